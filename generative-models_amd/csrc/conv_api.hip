@@ -1,0 +1,82 @@
+// conv_api.hip -- C-ABI entry points for conv / transposed-conv forward and data gradient.
+// Every variant is one launch of conv_igemm_kernel with a different weight view / mode:
+//   conv fwd s1 -> MODE0, s2 -> MODE1 ; conv dgrad s1 -> MODE0 with flipped taps and [c][m] weights,
+//   s2 -> MODE2 ; deconv fwd -> MODE2 ; deconv dgrad -> MODE1.
+#include "conv_igemm.h"
+
+static int conv_common_checks(int N, int Cin, int H, int W, int Cout, int ksize) {
+  if (N <= 0 || Cin <= 0 || Cout <= 0) return GMK_E_SHAPE;
+  if (!gmk_is_pow2(H) || !gmk_is_pow2(W) || H < 4 || W < 4 || W > 128) return GMK_E_SHAPE;
+  if (ksize != 3 && ksize != 5) return GMK_E_UNSUPPORTED;
+  return GMK_OK;
+}
+
+static int dispatch(ConvGeom& g, int ksize, int mode, hipStream_t s) {
+  return ksize == 3 ? gmk_launch_conv_k3(g, mode, s) : gmk_launch_conv_k5(g, mode, s);
+}
+
+extern "C" int gmk_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* dact, int N,
+                              int Cin, int H, int W, int Cout, int ksize, int stride, int act, gmk_stream_t stream) {
+  GMK_REQUIRE(x && w && y, GMK_E_NULL);
+  int rc = conv_common_checks(N, Cin, H, W, Cout, ksize);
+  if (rc) return rc;
+  GMK_REQUIRE(stride == 1 || stride == 2, GMK_E_UNSUPPORTED);
+  GMK_REQUIRE(act >= GMK_ACT_NONE && act <= GMK_ACT_MISH, GMK_E_UNSUPPORTED);
+  const int KK = ksize * ksize;
+  ConvGeom g{};
+  g.x = x; g.w = w; g.bias = bias; g.dact_in = nullptr; g.y = y; g.dact_out = dact;
+  g.N = N; g.C = Cin; g.M = Cout; g.IH = H; g.IW = W; g.OH = H / stride; g.OW = W / stride;
+  g.BW = g.OW; g.lgBW = gmk_ilog2(g.BW); g.lgBHW = gmk_ilog2((int64_t)g.OH * g.OW);
+  g.total_base = (long long)N * g.OH * g.OW;
+  g.w_layout = 0; g.w_m_stride = Cin * KK; g.w_c_stride = KK; g.flip = 0; g.act = act; g.epi = 0;
+  return dispatch(g, ksize, stride == 1 ? 0 : 1, (hipStream_t)stream);
+}
+
+extern "C" int gmk_conv2d_dgrad(const float* dy, const float* w, const float* dact_in, float* dx, int N, int Cin,
+                                int H, int W, int Cout, int ksize, int stride, gmk_stream_t stream) {
+  GMK_REQUIRE(dy && w && dx, GMK_E_NULL);
+  int rc = conv_common_checks(N, Cin, H, W, Cout, ksize);
+  if (rc) return rc;
+  GMK_REQUIRE(stride == 1 || stride == 2, GMK_E_UNSUPPORTED);
+  const int KK = ksize * ksize;
+  ConvGeom g{};
+  g.x = dy; g.w = w; g.bias = nullptr; g.dact_in = dact_in; g.y = dx; g.dact_out = nullptr;
+  g.N = N; g.C = Cout; g.M = Cin; g.IH = H / stride; g.IW = W / stride; g.OH = H; g.OW = W;
+  g.BW = W / stride; g.lgBW = gmk_ilog2(g.BW); g.lgBHW = gmk_ilog2((int64_t)g.IH * g.IW);
+  g.total_base = (long long)N * g.IH * g.IW;
+  g.w_layout = 1; g.w_m_stride = KK; g.w_c_stride = Cin * KK; g.flip = stride == 1 ? 1 : 0; g.act = 0; g.epi = 1;
+  return dispatch(g, ksize, stride == 1 ? 0 : 2, (hipStream_t)stream);
+}
+
+extern "C" int gmk_deconv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* dact, int N,
+                                int Cin, int H, int W, int Cout, int ksize, int act, gmk_stream_t stream) {
+  GMK_REQUIRE(x && w && y, GMK_E_NULL);
+  int rc = conv_common_checks(N, Cin, H, W, Cout, ksize);
+  if (rc) return rc;
+  GMK_REQUIRE(W <= 64, GMK_E_SHAPE);
+  GMK_REQUIRE(act >= GMK_ACT_NONE && act <= GMK_ACT_MISH, GMK_E_UNSUPPORTED);
+  const int KK = ksize * ksize;
+  ConvGeom g{};
+  g.x = x; g.w = w; g.bias = bias; g.dact_in = nullptr; g.y = y; g.dact_out = dact;
+  g.N = N; g.C = Cin; g.M = Cout; g.IH = H; g.IW = W; g.OH = 2 * H; g.OW = 2 * W;
+  g.BW = W; g.lgBW = gmk_ilog2(W); g.lgBHW = gmk_ilog2((int64_t)H * W);
+  g.total_base = (long long)N * H * W;
+  g.w_layout = 1; g.w_m_stride = KK; g.w_c_stride = Cout * KK; g.flip = 0; g.act = act; g.epi = 0;
+  return dispatch(g, ksize, 2, (hipStream_t)stream);
+}
+
+extern "C" int gmk_deconv2d_dgrad(const float* dy, const float* w, const float* dact_in, float* dx, int N, int Cin,
+                                  int H, int W, int Cout, int ksize, gmk_stream_t stream) {
+  GMK_REQUIRE(dy && w && dx, GMK_E_NULL);
+  int rc = conv_common_checks(N, Cin, H, W, Cout, ksize);
+  if (rc) return rc;
+  GMK_REQUIRE(W <= 64, GMK_E_SHAPE);
+  const int KK = ksize * ksize;
+  ConvGeom g{};
+  g.x = dy; g.w = w; g.bias = nullptr; g.dact_in = dact_in; g.y = dx; g.dact_out = nullptr;
+  g.N = N; g.C = Cout; g.M = Cin; g.IH = 2 * H; g.IW = 2 * W; g.OH = H; g.OW = W;
+  g.BW = W; g.lgBW = gmk_ilog2(W); g.lgBHW = gmk_ilog2((int64_t)H * W);
+  g.total_base = (long long)N * H * W;
+  g.w_layout = 0; g.w_m_stride = Cout * KK; g.w_c_stride = KK; g.flip = 0; g.act = 0; g.epi = 1;
+  return dispatch(g, ksize, 1, (hipStream_t)stream);
+}

@@ -1,0 +1,246 @@
+// conv_igemm.h -- implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).
+//
+// One kernel template covers every "gather" shaped conv of the path:
+//   MODE 0  stride-1 conv            (conv fwd; conv dgrad with flipped taps)
+//   MODE 1  stride-2 conv            (downsample fwd; transposed-conv dgrad)
+//   MODE 2  stride-2 transposed conv (deconv fwd; stride-2 conv dgrad), computed per output
+//           parity class so that only the taps that really contribute are multiplied.
+//
+// GEMM view: D[m][p] = sum_{c,t} Wsel[m][c][t] * X[c][p shifted by tap t]
+//   A operand (MFMA rows, 32 per tile)  = weights  (m = output channel of this op)
+//   B operand (MFMA cols, 32 per tile)  = pixels   -> the accumulator has the pixel on the lane,
+//                                                    so NCHW stores are 128-B coalesced rows.
+// "Base grid": output pixels for MODE 0/1, input pixels for MODE 2 (each base position yields the
+// four outputs (2y+py, 2x+px)).  A block owns PT consecutive base positions (whole rows, possibly
+// several images) x MB output channels; the input patch (with halo, zero padded) of CK input
+// channels and the matching weight slice are staged in LDS per K-chunk.
+#pragma once
+#include "gmk_common.h"
+
+struct ConvGeom {
+  const float* x; const float* w; const float* bias; const float* dact_in;
+  float* y; float* dact_out;
+  int N, C, M;
+  int IH, IW, OH, OW;
+  int BW, lgBW, lgBHW;
+  long long total_base;
+  int w_layout;  // 0: weights addressed [m][c][t] (c,t contiguous per m); 1: [c][m][t]
+  int w_m_stride, w_c_stride, flip;
+  int act, epi;  // epi 0: +bias, act (and act' to dact_out); 1: * dact_in (dgrad)
+  int seg_px, lg_seg_px, nseg;
+  int PR, PC, PS, npos;
+};
+
+#define CONV_MAXSLOT 4
+
+template <int MODE, int KS, int CK, int WM, int MT>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
+  constexpr int WP = 4 / WM, PT = WP * 32, MB = WM * MT * 32, KK = KS * KS, KC = CK * KK, WS = KC | 1;
+  constexpr int PAD = (KS - 1) / 2;
+  constexpr int NCLS = (MODE == 2) ? 4 : 1;
+  constexpr int SB = (MODE == 1) ? 2 : 1;
+  constexpr int TLO = (MODE == 2) ? (KS - 1 - PAD) / 2 : 0;
+  constexpr int ORG = (MODE == 2) ? TLO : PAD;  // patch origin offset (rows/cols before the base position)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Wl = smem;
+  float* Xl = smem + MB * WS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WP, wp = wave % WP;
+  const int h = lane >> 5, j = lane & 31;
+  const long long p0 = (long long)blockIdx.x * PT;
+  const int m0 = blockIdx.y * MB;
+  const int BHW = 1 << g.lgBHW;
+  const int PR = g.PR, PC = g.PC, PS = g.PS;
+  const int IHW = g.IH * g.IW;
+
+  // ---- per-thread patch slots (position decode done once; channels advance by IHW / PS) ----
+  long long s_goff[CONV_MAXSLOT];
+  int s_loff[CONV_MAXSLOT];
+#pragma unroll
+  for (int k = 0; k < CONV_MAXSLOT; ++k) {
+    int e = tid + k * 256;
+    s_goff[k] = -1;
+    s_loff[k] = -1;
+    if (e < g.npos) {
+      int seg = e / (PR * PC), r = e % (PR * PC);
+      int prow = r / PC, pcol = r % PC;
+      long long P = p0 + (long long)seg * g.seg_px;
+      long long n = P >> g.lgBHW;
+      int r0 = ((int)(P & (BHW - 1))) >> g.lgBW;
+      int iy = r0 * SB + prow - ORG, ix = pcol - ORG;
+      s_loff[k] = seg * CK * PS + prow * PC + pcol;
+      if (n < g.N && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW)
+        s_goff[k] = (n * g.C) * (long long)IHW + iy * g.IW + ix;
+    }
+  }
+
+  // ---- lane bases for the MFMA operand reads ----
+  const int q = wp * 32 + j;  // base position within the block
+  const int seg = q >> g.lg_seg_px, qs = q & (g.seg_px - 1);
+  const int br = qs >> g.lgBW, bx = qs & (g.BW - 1);
+  const int bbase = seg * CK * PS + h * PS + (br * SB) * PC + bx * SB;
+  const int abase = (wm * MT * 32 + j) * WS + h * KK;
+
+  f32x16 acc[NCLS][MT];
+#pragma unroll
+  for (int c = 0; c < NCLS; ++c)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][i][r] = 0.f;
+
+  for (int c0 = 0; c0 < g.C; c0 += CK) {
+    __syncthreads();
+    // stage the input patch chunk
+#pragma unroll
+    for (int k = 0; k < CONV_MAXSLOT; ++k) {
+      if (s_loff[k] >= 0) {
+#pragma unroll
+        for (int c = 0; c < CK; ++c) {
+          float v = 0.f;
+          if (s_goff[k] >= 0 && c0 + c < g.C) v = g.x[s_goff[k] + (long long)(c0 + c) * IHW];
+          Xl[s_loff[k] + c * PS] = v;
+        }
+      }
+    }
+    // stage the weight chunk  Wl[m][c*KK + t]
+    for (int e = tid; e < MB * KC; e += 256) {
+      int m, c, t;
+      if (g.w_layout == 0) { m = e / KC; int r = e % KC; c = r / KK; t = r % KK; }
+      else { c = e / (MB * KK); int r = e % (MB * KK); m = r / KK; t = r % KK; }
+      const int gm = m0 + m, gc = c0 + c;
+      float v = 0.f;
+      if (gm < g.M && gc < g.C) v = g.w[(long long)gm * g.w_m_stride + (long long)gc * g.w_c_stride + t];
+      const int tt = g.flip ? (KK - 1 - t) : t;
+      Wl[m * WS + c * KK + tt] = v;
+    }
+    __syncthreads();
+    // MFMA over the chunk: k-step = (channel pair cp, tap t); lane half h takes channel 2cp+h
+#pragma unroll
+    for (int cp = 0; cp < CK / 2; ++cp) {
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        const int ky = t / KS, kx = t % KS;
+        int boff, cls;
+        if (MODE == 2) {
+          const int py = (ky + PAD) & 1, px = (kx + PAD) & 1;
+          const int dy = (py + PAD - ky) / 2, dx = (px + PAD - kx) / 2;
+          boff = (dy + TLO) * PC + (dx + TLO);
+          cls = py * 2 + px;
+        } else {
+          boff = ky * PC + kx;
+          cls = 0;
+        }
+        const float b = Xl[bbase + cp * 2 * PS + boff];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const float a = Wl[abase + i * 32 * WS + cp * 2 * KK + t];
+          acc[cls][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[cls][i], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue ----
+  const long long P = p0 + q;
+  if (P >= g.total_base) return;
+  const long long n = P >> g.lgBHW;
+  const int rem = (int)(P & (BHW - 1));
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (m >= g.M) continue;
+      if (MODE != 2) {
+        const long long idx = (n * g.M + m) * (long long)BHW + rem;
+        float v = acc[0][i][r];
+        if (g.epi == 0) {
+          if (g.bias) v += g.bias[m];
+          float a, d;
+          gmk_act_fwd(g.act, v, a, d);
+          g.y[idx] = a;
+          if (g.dact_out) g.dact_out[idx] = d;
+        } else {
+          if (g.dact_in) v *= g.dact_in[idx];
+          g.y[idx] = v;
+        }
+      } else {
+        const int by = rem >> g.lgBW, bxx = rem & (g.BW - 1);
+        const float bv = (g.epi == 0 && g.bias) ? g.bias[m] : 0.f;
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+          const long long idx = (n * g.M + m) * (long long)(4 * BHW) + (long long)(2 * by + py) * (2 * g.BW) + 2 * bxx;
+          float2 v = make_float2(acc[py * 2][i][r], acc[py * 2 + 1][i][r]);
+          if (g.epi == 0) {
+            float a0, d0, a1, d1;
+            gmk_act_fwd(g.act, v.x + bv, a0, d0);
+            gmk_act_fwd(g.act, v.y + bv, a1, d1);
+            *(float2*)(g.y + idx) = make_float2(a0, a1);
+            if (g.dact_out) *(float2*)(g.dact_out + idx) = make_float2(d0, d1);
+          } else {
+            if (g.dact_in) { float2 dd = *(const float2*)(g.dact_in + idx); v.x *= dd.x; v.y *= dd.y; }
+            *(float2*)(g.y + idx) = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// Host-side launcher (one instantiation set per kernel size, defined in conv_igemm_k{3,5}.hip)
+int gmk_launch_conv_k3(ConvGeom& g, int mode, hipStream_t s);
+int gmk_launch_conv_k5(ConvGeom& g, int mode, hipStream_t s);
+
+template <int KS>
+static int gmk_launch_conv_impl(ConvGeom& g, int mode, hipStream_t s) {
+  constexpr int KK = KS * KS, PAD = (KS - 1) / 2;
+  const int BH = (1 << g.lgBHW) / g.BW;
+  // tile choice: 64 out-channels x 128 base positions when that still gives >= 2 blocks per CU,
+  // else 64 x 64; 32 x 128 when the op has <= 32 output channels (dec.conv3: 3).
+  int WM, MT;
+  if (g.M <= 32) { WM = 1; MT = 1; }
+  else if (mode != 2 && g.total_base / 128 >= 512) { WM = 1; MT = 2; }  // MODE2 keeps 4 parity accumulators
+  else { WM = 2; MT = 1; }
+  const int WP = 4 / WM, PT = WP * 32, MB = WM * MT * 32;
+  if (g.BW > PT) return GMK_E_SHAPE;
+  const int CK = (mode == 0 && g.C < 8) ? 4 : 8;
+  const int bhw = 1 << g.lgBHW;
+  g.seg_px = PT < bhw ? PT : bhw;
+  g.lg_seg_px = gmk_ilog2(g.seg_px);
+  g.nseg = PT / g.seg_px;
+  const int seg_rows = g.seg_px / g.BW;
+  if (mode == 0) { g.PR = seg_rows + KS - 1; g.PC = g.BW + KS - 1; }
+  else if (mode == 1) { g.PR = 2 * seg_rows + KS - 2; g.PC = 2 * g.BW + KS - 2; }
+  else { const int tlo = (KS - 1 - PAD) / 2, thi = (PAD + 1) / 2; g.PR = seg_rows + tlo + thi; g.PC = g.BW + tlo + thi; }
+  g.PS = g.PR * g.PC;
+  g.npos = g.nseg * g.PR * g.PC;
+  if (g.npos > 256 * CONV_MAXSLOT) return GMK_E_SHAPE;
+  (void)BH;
+  const size_t lds = sizeof(float) * ((size_t)MB * ((CK * KK) | 1) + (size_t)g.nseg * CK * g.PS);
+  if (lds > 160 * 1024) return GMK_E_SHAPE;
+  dim3 grid((unsigned)((g.total_base + PT - 1) / PT), (unsigned)((g.M + MB - 1) / MB));
+#define GMK_CONV_LAUNCH(MODE_, CK_, WM_, MT_)                                                              \
+  do {                                                                                                     \
+    auto kern = conv_igemm_kernel<MODE_, KS, CK_, WM_, MT_>;                                               \
+    if (lds > 64 * 1024) {                                                                                 \
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return (int)e;                                                                  \
+    }                                                                                                      \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, g);                                                  \
+  } while (0)
+#define GMK_CONV_TILE(MODE_, CK_)                                 \
+  do {                                                            \
+    if (WM == 1 && MT == 2) GMK_CONV_LAUNCH(MODE_, CK_, 1, 2);    \
+    else if (WM == 2) GMK_CONV_LAUNCH(MODE_, CK_, 2, 1);          \
+    else GMK_CONV_LAUNCH(MODE_, CK_, 1, 1);                       \
+  } while (0)
+  if (mode == 0) { if (CK == 4) GMK_CONV_TILE(0, 4); else GMK_CONV_TILE(0, 8); }
+  else if (mode == 1) GMK_CONV_TILE(1, 8);
+  else GMK_CONV_TILE(2, 8);
+#undef GMK_CONV_TILE
+#undef GMK_CONV_LAUNCH
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? GMK_OK : (int)e;
+}

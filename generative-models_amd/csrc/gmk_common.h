@@ -1,0 +1,95 @@
+// gmk_common.h -- shared device/host helpers for libgmk (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "../../include/gmk.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+#define GMK_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t e__ = hipGetLastError();                      \
+    if (e__ != hipSuccess) return (int)e__;                  \
+  } while (0)
+
+#define GMK_REQUIRE(cond, code) \
+  do {                          \
+    if (!(cond)) return (code); \
+  } while (0)
+
+static inline bool gmk_is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
+static inline int gmk_ilog2(int64_t v) {
+  int l = 0;
+  while ((1ll << l) < v) ++l;
+  return l;
+}
+static inline bool gmk_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// ---- activations: value and derivative, PyTorch default parameters --------------------
+// (reference: /root/reference/utils.py:49-66)
+__device__ __forceinline__ float gmk_sigmoidf(float z) { return 1.0f / (1.0f + expf(-z)); }
+
+__device__ __forceinline__ void gmk_act_fwd(int act, float z, float& a, float& d) {
+  switch (act) {
+    case GMK_ACT_RELU:
+      a = z > 0.f ? z : 0.f;
+      d = z > 0.f ? 1.f : 0.f;
+      break;
+    case GMK_ACT_LEAKY_RELU:
+      a = z > 0.f ? z : 0.01f * z;
+      d = z > 0.f ? 1.f : 0.01f;
+      break;
+    case GMK_ACT_ELU: {
+      float e = expm1f(z);
+      a = z > 0.f ? z : e;
+      d = z > 0.f ? 1.f : e + 1.f;
+      break;
+    }
+    case GMK_ACT_SELU: {
+      const float sc = 1.0507009873554804934193349852946f, al = 1.6732632423543772848170429916717f;
+      float e = expm1f(z);
+      a = sc * (z > 0.f ? z : al * e);
+      d = sc * (z > 0.f ? 1.f : al * (e + 1.f));
+      break;
+    }
+    case GMK_ACT_GELU: {
+      float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752440f));
+      float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
+      a = z * cdf;
+      d = cdf + z * pdf;
+      break;
+    }
+    case GMK_ACT_SILU: {
+      float s = 1.0f / (1.0f + expf(-z));
+      a = z * s;
+      d = s * (1.f + z * (1.f - s));
+      break;
+    }
+    case GMK_ACT_MISH: {
+      float sp = z > 20.f ? z : log1pf(expf(z));
+      float th = tanhf(sp);
+      float s = 1.0f / (1.0f + expf(-z));
+      a = z * th;
+      d = th + z * (1.f - th * th) * s;
+      break;
+    }
+    default:
+      a = z;
+      d = 1.f;
+  }
+}
+
+// wave64 sum reduction (all lanes get the result in lane 0; use after per-thread partials)
+__device__ __forceinline__ double gmk_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float gmk_wave_sumf(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}

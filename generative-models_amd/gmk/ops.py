@@ -1,0 +1,169 @@
+"""Tensor-level wrappers over the C ABI (no autograd here; see gmk/functional.py).
+
+Every function takes contiguous fp32 CUDA tensors, allocates its outputs with torch (device
+memory plumbing), and launches on torch's current stream.
+"""
+import torch
+
+from ._lib import lib, check, act_id
+
+_ws_cache = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError("gmk ops need contiguous fp32 CUDA tensors")
+
+
+def workspace(nbytes, device):
+    """A cached per-device byte workspace (grown on demand; single stream use)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def conv2d_fwd(x, w, bias, stride=1, act=None, want_dact=False):
+    _chk(x, w, bias)
+    N, Cin, H, W = x.shape
+    Cout, _, k, _ = w.shape
+    y = torch.empty((N, Cout, H // stride, W // stride), device=x.device, dtype=torch.float32)
+    dact = torch.empty_like(y) if want_dact else None
+    check(lib().gmk_conv2d_fwd(_p(x), _p(w), _p(bias), _p(y), _p(dact), N, Cin, H, W, Cout, k, stride, act_id(act), _stream()))
+    return (y, dact) if want_dact else y
+
+
+def conv2d_dgrad(dy, w, x_shape, stride=1, dact_in=None):
+    _chk(dy, w, dact_in)
+    N, Cin, H, W = x_shape
+    Cout, _, k, _ = w.shape
+    dx = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
+    check(lib().gmk_conv2d_dgrad(_p(dy), _p(w), _p(dact_in), _p(dx), N, Cin, H, W, Cout, k, stride, _stream()))
+    return dx
+
+
+def conv2d_wgrad(dy, x, ksize, stride=1, want_bias=True):
+    _chk(dy, x)
+    N, Cin, H, W = x.shape
+    Cout = dy.shape[1]
+    dw = torch.empty((Cout, Cin, ksize, ksize), device=x.device, dtype=torch.float32)
+    db = torch.empty((Cout,), device=x.device, dtype=torch.float32) if want_bias else None
+    nb = lib().gmk_conv2d_wgrad_workspace_bytes(N, Cin, H, W, Cout, ksize, stride)
+    ws = workspace(nb, x.device)
+    check(lib().gmk_conv2d_wgrad(_p(dy), _p(x), _p(dw), _p(db), N, Cin, H, W, Cout, ksize, stride, _p(ws), ws.numel(), _stream()))
+    return dw, db
+
+
+def deconv2d_fwd(x, w, bias, act=None, want_dact=False):
+    _chk(x, w, bias)
+    N, Cin, H, W = x.shape
+    _, Cout, k, _ = w.shape
+    y = torch.empty((N, Cout, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+    dact = torch.empty_like(y) if want_dact else None
+    check(lib().gmk_deconv2d_fwd(_p(x), _p(w), _p(bias), _p(y), _p(dact), N, Cin, H, W, Cout, k, act_id(act), _stream()))
+    return (y, dact) if want_dact else y
+
+
+def deconv2d_dgrad(dy, w, x_shape, dact_in=None):
+    _chk(dy, w, dact_in)
+    N, Cin, H, W = x_shape
+    _, Cout, k, _ = w.shape
+    dx = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
+    check(lib().gmk_deconv2d_dgrad(_p(dy), _p(w), _p(dact_in), _p(dx), N, Cin, H, W, Cout, k, _stream()))
+    return dx
+
+
+def deconv2d_wgrad(dy, x, ksize, want_bias=True):
+    _chk(dy, x)
+    N, Cin, H, W = x.shape
+    Cout = dy.shape[1]
+    dw = torch.empty((Cin, Cout, ksize, ksize), device=x.device, dtype=torch.float32)
+    db = torch.empty((Cout,), device=x.device, dtype=torch.float32) if want_bias else None
+    nb = lib().gmk_deconv2d_wgrad_workspace_bytes(N, Cin, H, W, Cout, ksize)
+    ws = workspace(nb, x.device)
+    check(lib().gmk_deconv2d_wgrad(_p(dy), _p(x), _p(dw), _p(db), N, Cin, H, W, Cout, ksize, _p(ws), ws.numel(), _stream()))
+    return dw, db
+
+
+def linear_fwd(x, w, bias, act=None, want_dact=False):
+    _chk(x, w, bias)
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    dact = torch.empty_like(y) if want_dact else None
+    ws = workspace(lib().gmk_linear_workspace_bytes(M, K, N), x.device)
+    check(lib().gmk_linear_fwd(_p(x), _p(w), _p(bias), _p(y), _p(dact), M, K, N, act_id(act), _p(ws), ws.numel(), _stream()))
+    return (y, dact) if want_dact else y
+
+
+def linear_dgrad(dy, w, dact_in=None):
+    _chk(dy, w, dact_in)
+    M, N = dy.shape
+    K = w.shape[1]
+    dx = torch.empty((M, K), device=dy.device, dtype=torch.float32)
+    ws = workspace(lib().gmk_linear_workspace_bytes(M, K, N), dy.device)
+    check(lib().gmk_linear_dgrad(_p(dy), _p(w), _p(dact_in), _p(dx), M, K, N, _p(ws), ws.numel(), _stream()))
+    return dx
+
+
+def linear_wgrad(dy, x, want_bias=True):
+    _chk(dy, x)
+    M, N = dy.shape
+    K = x.shape[1]
+    dw = torch.empty((N, K), device=x.device, dtype=torch.float32)
+    db = torch.empty((N,), device=x.device, dtype=torch.float32) if want_bias else None
+    ws = workspace(lib().gmk_linear_workspace_bytes(M, K, N), x.device)
+    check(lib().gmk_linear_wgrad(_p(dy), _p(x), _p(dw), _p(db), M, K, N, _p(ws), ws.numel(), _stream()))
+    return dw, db
+
+
+def reparam_fwd(stats, eps):
+    _chk(stats, eps)
+    B, L, _ = stats.shape
+    z = torch.empty((B, L), device=stats.device, dtype=torch.float32)
+    check(lib().gmk_reparam_fwd(_p(stats), _p(eps), _p(z), B, L, _stream()))
+    return z
+
+
+def reparam_bwd(dz, stats, eps, dstats=None):
+    _chk(dz, stats, eps, dstats)
+    B, L, _ = stats.shape
+    acc = 1
+    if dstats is None:
+        dstats = torch.empty_like(stats)
+        acc = 0
+    check(lib().gmk_reparam_bwd(_p(dz), _p(stats), _p(eps), _p(dstats), B, L, acc, _stream()))
+    return dstats
+
+
+LOSS_SIGMOID, LOSS_MSE_PRIOR = 1, 2
+
+
+def vae_loss_fwd_bwd(pre, image, stats, beta, sigmoid=True, mse_prior=False, want_recon=False):
+    """Returns (losses[3] = rec, kl, total ; dpre ; dstats or None ; recon or None)."""
+    _chk(pre, image, stats)
+    B = pre.shape[0]
+    chw = pre.numel() // B
+    L = 0 if stats is None else stats.shape[1]
+    dpre = torch.empty_like(pre)
+    dstats = None if stats is None else torch.empty_like(stats)
+    recon = torch.empty_like(pre) if want_recon else None
+    losses = torch.empty(3, device=pre.device, dtype=torch.float32)
+    ws = workspace(lib().gmk_vae_loss_workspace_bytes(), pre.device)
+    flags = (LOSS_SIGMOID if sigmoid else 0) | (LOSS_MSE_PRIOR if mse_prior else 0)
+    check(lib().gmk_vae_loss_fwd_bwd(_p(pre), _p(image), _p(stats), _p(recon), _p(dpre), _p(dstats), _p(losses),
+                                     B, chw, L, float(beta), flags, _p(ws), ws.numel(), _stream()))
+    return losses, dpre, dstats, recon

@@ -1,0 +1,136 @@
+/* gmk.h -- C ABI of libgmk.so: hand-written gfx950 (MI355X) kernels for the hot path of
+ * michaelklachko/generative-models: the CIFAR-10 conv autoencoder / VAE train step and the
+ * FID / inception feature statistics.
+ *
+ * The reference has no FFI of its own (it is eager PyTorch); each entry point below replaces
+ * the PyTorch call(s) cited in its comment (file:line under /root/reference).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes; every buffer (inputs, outputs, workspace) is DEVICE memory owned by
+ *     the caller; the library never allocates, frees or retains a pointer;
+ *   - tensors are fp32, contiguous, NCHW (activations), OIHW (conv weights), IOHW (transposed-conv
+ *     weights), [out][in] (linear weights): the layouts of the reference's state_dict;
+ *   - asynchronous launch on `stream` (a hipStream_t passed as void*; NULL = default stream),
+ *     no internal synchronisation, no global mutable state;
+ *   - return 0 on success, a negative GMK_E_* on a rejected argument, a positive hipError_t if a
+ *     launch failed; gmk_strerror() names either.
+ *   - spatial sizes must be powers of two (the reference fixes 32x32; 64x64 for config 5).
+ */
+#ifndef GMK_H
+#define GMK_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gmk_stream_t;
+
+enum gmk_error {
+  GMK_OK = 0,
+  GMK_E_SHAPE = -1,       /* unsupported / inconsistent shape */
+  GMK_E_ALIGN = -2,       /* pointer not 16-byte aligned */
+  GMK_E_UNSUPPORTED = -3, /* unsupported option (kernel size, activation, mode) */
+  GMK_E_WORKSPACE = -4,   /* workspace too small */
+  GMK_E_NULL = -5         /* required pointer is NULL */
+};
+
+/* /root/reference/utils.py:49-66 get_activation_function */
+enum gmk_act {
+  GMK_ACT_NONE = 0,
+  GMK_ACT_RELU = 1,
+  GMK_ACT_LEAKY_RELU = 2,
+  GMK_ACT_ELU = 3,
+  GMK_ACT_SELU = 4,
+  GMK_ACT_GELU = 5,
+  GMK_ACT_SILU = 6,
+  GMK_ACT_MISH = 7
+};
+
+int gmk_version(void);
+const char* gmk_strerror(int code);
+
+/* ---------------------------------------------------------------- convolutions ----------
+ * Implicit-GEMM fp32-MFMA kernels (v_mfma_f32_32x32x2_f32), LDS-staged input patch + weights.
+ * ksize in {3,5}, padding (ksize-1)/2, stride in {1,2}.
+ *
+ * gmk_conv2d_fwd: y = act(conv2d(x, w) + bias); if dact != NULL also writes act'(pre-activation)
+ *   (the backward pass multiplies by it instead of re-evaluating erf/exp).
+ *   replaces nn.Conv2d + activation, models/autoencoders.py:33-38,46-54,82-84,98,102,106
+ *   x (N,Cin,H,W)  w (Cout,Cin,k,k)  bias (Cout) or NULL  y,dact (N,Cout,H/stride,W/stride)
+ */
+int gmk_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* dact,
+                   int N, int Cin, int H, int W, int Cout, int ksize, int stride, int act,
+                   gmk_stream_t stream);
+/* gmk_conv2d_dgrad: dx = conv2d_input_grad(dy, w) * dact_in  (dact_in = act' of the layer that
+ *   produced x, NULL for none).  replaces autograd of nn.Conv2d (main.py:51).
+ *   dy (N,Cout,H/stride,W/stride)  dx,dact_in (N,Cin,H,W) */
+int gmk_conv2d_dgrad(const float* dy, const float* w, const float* dact_in, float* dx,
+                     int N, int Cin, int H, int W, int Cout, int ksize, int stride,
+                     gmk_stream_t stream);
+/* gmk_conv2d_wgrad: dw (Cout,Cin,k,k) = weight grad, dbias (Cout) = bias grad (NULL to skip).
+ *   Deterministic: per-block partial slabs in `ws`, summed in fixed order.
+ *   ws_bytes >= gmk_conv2d_wgrad_workspace_bytes(...). */
+size_t gmk_conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int ksize, int stride);
+int gmk_conv2d_wgrad(const float* dy, const float* x, float* dw, float* dbias,
+                     int N, int Cin, int H, int W, int Cout, int ksize, int stride,
+                     void* ws, size_t ws_bytes, gmk_stream_t stream);
+
+/* Transposed convolution, stride 2, padding (k-1)/2, output_padding 1: (H,W) -> (2H,2W).
+ *   replaces nn.ConvTranspose2d + activation, models/autoencoders.py:86-87,100,104
+ *   x (N,Cin,H,W)  w (Cin,Cout,k,k)  y,dact (N,Cout,2H,2W) */
+int gmk_deconv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* dact,
+                     int N, int Cin, int H, int W, int Cout, int ksize, int act, gmk_stream_t stream);
+int gmk_deconv2d_dgrad(const float* dy, const float* w, const float* dact_in, float* dx,
+                       int N, int Cin, int H, int W, int Cout, int ksize, gmk_stream_t stream);
+size_t gmk_deconv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int ksize);
+int gmk_deconv2d_wgrad(const float* dy, const float* x, float* dw, float* dbias,
+                       int N, int Cin, int H, int W, int Cout, int ksize,
+                       void* ws, size_t ws_bytes, gmk_stream_t stream);
+
+/* ---------------------------------------------------------------- linear ----------------
+ * replaces nn.Linear (+ activation), models/autoencoders.py:41,57,81,95 and its autograd.
+ *   x (M,K)  w (N,K)  bias (N)  y,dact (M,N).  Split-K partials (deterministic) use `ws`. */
+size_t gmk_linear_workspace_bytes(int M, int K, int N);
+int gmk_linear_fwd(const float* x, const float* w, const float* bias, float* y, float* dact,
+                   int M, int K, int N, int act, void* ws, size_t ws_bytes, gmk_stream_t stream);
+/* dx (M,K) = dy (M,N) @ w (N,K), times dact_in (M,K) if not NULL */
+int gmk_linear_dgrad(const float* dy, const float* w, const float* dact_in, float* dx,
+                     int M, int K, int N, void* ws, size_t ws_bytes, gmk_stream_t stream);
+/* dw (N,K) = dy^T @ x ; dbias (N) = column sums of dy (NULL to skip) */
+int gmk_linear_wgrad(const float* dy, const float* x, float* dw, float* dbias,
+                     int M, int K, int N, void* ws, size_t ws_bytes, gmk_stream_t stream);
+
+/* ---------------------------------------------------------------- VAE glue --------------
+ * gmk_reparam_fwd: z[b,l] = stats[b,l,0] + exp(0.5*stats[b,l,1]) * eps[b,l]
+ *   replaces models/autoencoders.py:169-176.  stats (B,L,2) interleaved mu/log_var. */
+int gmk_reparam_fwd(const float* stats, const float* eps, float* z, int64_t B, int64_t L,
+                    gmk_stream_t stream);
+/* gmk_reparam_bwd: dstats[b,l,0] += dz ; dstats[b,l,1] += dz*eps*0.5*exp(0.5*log_var)
+ *   (accumulates onto the KL gradient written by gmk_vae_loss_fwd_bwd; if accumulate==0 it
+ *   overwrites).  autograd of models/autoencoders.py:171-176. */
+int gmk_reparam_bwd(const float* dz, const float* stats, const float* eps, float* dstats,
+                    int64_t B, int64_t L, int accumulate, gmk_stream_t stream);
+
+/* gmk_vae_loss_fwd_bwd: ONE coalesced HBM-bound kernel (+ a 1-block finalize) computing
+ *   recon = sigmoid(pre) (if GMK_LOSS_SIGMOID, models/autoencoders.py:109-110),
+ *   rec  = mean((recon-image)^2)                         (main.py:31),
+ *   kl   = mean_b(-0.5*sum_l(1+lv-mu^2-exp(lv)))         (main.py:45)
+ *          or sum_l mu^2 + sum_l (sigma-1)^2 if GMK_LOSS_MSE_PRIOR (main.py:39-42),
+ *   total = rec + beta*kl                                 (main.py:47-48),
+ *   and their gradients: dpre = d total/d pre, dstats = beta * d kl/d stats.
+ *   pre,image,dpre,recon_out: (B, chw) ; stats,dstats: (B,L,2) (NULL when not variational).
+ *   recon_out may be NULL.  losses: 3 floats on device {rec, kl, total}.
+ *   ws: >= gmk_vae_loss_workspace_bytes() bytes. */
+enum { GMK_LOSS_SIGMOID = 1, GMK_LOSS_MSE_PRIOR = 2 };
+size_t gmk_vae_loss_workspace_bytes(void);
+int gmk_vae_loss_fwd_bwd(const float* pre, const float* image, const float* stats,
+                         float* recon_out, float* dpre, float* dstats, float* losses,
+                         int64_t B, int64_t chw, int64_t L, float beta, int flags,
+                         void* ws, size_t ws_bytes, gmk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMK_H */

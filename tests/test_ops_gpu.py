@@ -1,0 +1,199 @@
+"""GPU parity of every C-ABI op against the CPU oracle ops (torch functional, fp64 reference)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import detgen, ae_oracle
+
+pytestmark = pytest.mark.gpu
+
+ACTS = list(ae_oracle.ACTS)
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def T(name, shape, lo=-1.0, hi=1.0):
+    return torch.from_numpy(detgen.uniform(name, shape, lo, hi))
+
+
+def close(got, ref, tol=2e-5, name=""):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-30
+    assert err <= tol * scale, f"{name}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def act_and_grad(z, act):
+    z = z.clone().requires_grad_(True)
+    a = ae_oracle.act_forward(z, act)
+    (d,) = torch.autograd.grad(a.sum(), z)
+    return a.detach(), d.detach()
+
+
+CONV_SHAPES = [
+    # N, Cin, H, W, Cout, k, stride
+    (2, 3, 32, 32, 64, 3, 1),
+    (2, 64, 32, 32, 64, 3, 2),
+    (3, 64, 16, 16, 64, 3, 1),
+    (2, 64, 16, 16, 64, 3, 2),
+    (5, 64, 8, 8, 64, 3, 1),
+    (2, 64, 32, 32, 3, 3, 1),
+    (2, 16, 16, 16, 16, 3, 1),
+    (1, 8, 8, 8, 8, 5, 1),
+    (2, 8, 16, 16, 8, 5, 2),
+    (1, 16, 64, 64, 16, 3, 1),
+    (16, 64, 16, 16, 64, 3, 1),   # enough base positions for the 64x128 tile
+    (3, 24, 8, 8, 40, 3, 1),      # ragged channel counts
+]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+@pytest.mark.parametrize("act", ["gelu", None])
+def test_conv2d_fwd(shape, act):
+    from gmk import ops
+    N, Cin, H, W, Cout, k, s = shape
+    x = T(f"cx{shape}", (N, Cin, H, W))
+    w = T(f"cw{shape}", (Cout, Cin, k, k)) / np.sqrt(Cin * k * k)
+    b = T(f"cb{shape}", (Cout,))
+    pre = F.conv2d(x.double(), w.double(), b.double(), s, (k - 1) // 2)
+    y, dact = ops.conv2d_fwd(x.to(dev()), w.to(dev()), b.to(dev()), stride=s, act=act, want_dact=True)
+    if act is None:
+        close(y, pre, name="y")
+    else:
+        a, d = act_and_grad(pre, act)
+        close(y, a, name="y")
+        close(dact, d, tol=1e-4, name="dact")
+
+
+@pytest.mark.parametrize("act", ACTS)
+def test_activations_in_conv_epilogue(act):
+    from gmk import ops
+    x = T("ax", (2, 8, 8, 8), -3, 3)
+    w = T("aw", (8, 8, 3, 3), -1, 1)
+    b = T("ab", (8,), -2, 2)
+    pre = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    a, d = act_and_grad(pre, act)
+    y, dact = ops.conv2d_fwd(x.to(dev()), w.to(dev()), b.to(dev()), act=act, want_dact=True)
+    close(y, a, name="y")
+    close(dact, d, tol=1e-4, name="dact")
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv2d_dgrad_wgrad(shape):
+    from gmk import ops
+    N, Cin, H, W, Cout, k, s = shape
+    x = T(f"gx{shape}", (N, Cin, H, W)).double().requires_grad_(True)
+    w = (T(f"gw{shape}", (Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).double().requires_grad_(True)
+    b = T(f"gb{shape}", (Cout,)).double().requires_grad_(True)
+    dy = T(f"gdy{shape}", (N, Cout, H // s, W // s))
+    dact_in = T(f"gda{shape}", (N, Cin, H, W), 0.0, 1.0)
+    y = F.conv2d(x, w, b, s, (k - 1) // 2)
+    gx, gw, gb = torch.autograd.grad(y, (x, w, b), dy.double())
+    dx = ops.conv2d_dgrad(dy.to(dev()), w.detach().float().to(dev()), (N, Cin, H, W), stride=s, dact_in=dact_in.to(dev()))
+    close(dx, gx * dact_in.double(), name="dx")
+    dx2 = ops.conv2d_dgrad(dy.to(dev()), w.detach().float().to(dev()), (N, Cin, H, W), stride=s)
+    close(dx2, gx, name="dx(no dact)")
+    dw, db = ops.conv2d_wgrad(dy.to(dev()), x.detach().float().to(dev()), k, stride=s)
+    close(dw, gw, name="dw")
+    close(db, gb, name="db")
+
+
+DECONV_SHAPES = [(2, 64, 8, 8, 64, 3), (2, 64, 16, 16, 64, 3), (3, 16, 8, 8, 24, 3), (1, 8, 8, 8, 8, 5), (9, 64, 16, 16, 64, 3)]
+
+
+@pytest.mark.parametrize("shape", DECONV_SHAPES)
+def test_deconv2d_all(shape):
+    from gmk import ops
+    N, Cin, H, W, Cout, k = shape
+    p = (k - 1) // 2
+    x = T(f"dx{shape}", (N, Cin, H, W)).double().requires_grad_(True)
+    w = (T(f"dw{shape}", (Cin, Cout, k, k)) / np.sqrt(Cin * k * k)).double().requires_grad_(True)
+    b = T(f"db{shape}", (Cout,)).double().requires_grad_(True)
+    dy = T(f"ddy{shape}", (N, Cout, 2 * H, 2 * W))
+    pre = F.conv_transpose2d(x, w, b, 2, p, 1)
+    a, d = act_and_grad(pre.detach(), "gelu")
+    y, dact = ops.deconv2d_fwd(x.detach().float().to(dev()), w.detach().float().to(dev()), b.detach().float().to(dev()),
+                               act="gelu", want_dact=True)
+    close(y, a, name="y")
+    close(dact, d, tol=1e-4, name="dact")
+    gx, gw, gb = torch.autograd.grad(pre, (x, w, b), dy.double())
+    dxx = ops.deconv2d_dgrad(dy.to(dev()), w.detach().float().to(dev()), (N, Cin, H, W))
+    close(dxx, gx, name="dx")
+    dw, db = ops.deconv2d_wgrad(dy.to(dev()), x.detach().float().to(dev()), k)
+    close(dw, gw, name="dw")
+    close(db, gb, name="db")
+
+
+LIN_SHAPES = [(8, 4096, 512), (8, 256, 4096), (256, 4096, 512), (256, 256, 4096), (5, 100, 37), (50, 4096, 256)]
+
+
+@pytest.mark.parametrize("shape", LIN_SHAPES)
+def test_linear_all(shape):
+    from gmk import ops
+    M, K, N = shape
+    x = T(f"lx{shape}", (M, K)).double().requires_grad_(True)
+    w = (T(f"lw{shape}", (N, K)) / np.sqrt(K)).double().requires_grad_(True)
+    b = T(f"lb{shape}", (N,)).double().requires_grad_(True)
+    dy = T(f"ldy{shape}", (M, N))
+    pre = F.linear(x, w, b)
+    a, d = act_and_grad(pre.detach(), "gelu")
+    y, dact = ops.linear_fwd(x.detach().float().to(dev()), w.detach().float().to(dev()), b.detach().float().to(dev()),
+                             act="gelu", want_dact=True)
+    close(y, a, name="y")
+    close(dact, d, tol=1e-4, name="dact")
+    y0 = ops.linear_fwd(x.detach().float().to(dev()), w.detach().float().to(dev()), b.detach().float().to(dev()))
+    close(y0, pre, name="y(no act)")
+    gx, gw, gb = torch.autograd.grad(pre, (x, w, b), dy.double())
+    dact_in = T(f"lda{shape}", (M, K), 0.0, 1.0)
+    dx = ops.linear_dgrad(dy.to(dev()), w.detach().float().to(dev()), dact_in=dact_in.to(dev()))
+    close(dx, gx * dact_in.double(), name="dx")
+    dw, db = ops.linear_wgrad(dy.to(dev()), x.detach().float().to(dev()))
+    close(dw, gw, name="dw")
+    close(db, gb, name="db")
+
+
+@pytest.mark.parametrize("B,L", [(8, 256), (3, 16), (256, 256)])
+def test_reparam(B, L):
+    from gmk import ops
+    stats = T(f"rs{B}", (B, L, 2), -2, 2).double().requires_grad_(True)
+    eps = torch.from_numpy(detgen.normal(f"re{B}", (B, L)))
+    z = stats[:, :, 0] + torch.exp(0.5 * stats[:, :, 1]) * eps.double()
+    dz = T(f"rdz{B}", (B, L))
+    (gs,) = torch.autograd.grad(z, stats, dz.double())
+    zg = ops.reparam_fwd(stats.detach().float().to(dev()), eps.to(dev()))
+    close(zg, z, name="z")
+    ds = ops.reparam_bwd(dz.to(dev()), stats.detach().float().to(dev()), eps.to(dev()))
+    close(ds, gs, name="dstats")
+    base = T(f"rb{B}", (B, L, 2))
+    ds2 = ops.reparam_bwd(dz.to(dev()), stats.detach().float().to(dev()), eps.to(dev()), dstats=base.to(dev()).clone())
+    close(ds2, gs + base.double(), name="dstats(acc)")
+
+
+@pytest.mark.parametrize("B", [1, 8, 50, 256])
+@pytest.mark.parametrize("sigmoid", [True, False])
+@pytest.mark.parametrize("variational,mse_prior", [(True, False), (True, True), (False, False)])
+def test_vae_loss_fwd_bwd(B, sigmoid, variational, mse_prior):
+    from gmk import ops
+    L, beta = 256, 0.05
+    pre = T(f"vp{B}", (B, 3, 32, 32), -4, 4).double().requires_grad_(True)
+    img = T(f"vi{B}", (B, 3, 32, 32), 0, 1)
+    stats = T(f"vs{B}", (B, L, 2), -2, 2).double().requires_grad_(True) if variational else None
+    recon = torch.sigmoid(pre) if sigmoid else pre
+    rec, kl, total = ae_oracle.train_losses(recon, img.double(), stats, beta, variational=variational, mse_prior=mse_prior)
+    grads = torch.autograd.grad(total, (pre, stats) if variational else (pre,))
+    losses, dpre, dstats, rout = ops.vae_loss_fwd_bwd(pre.detach().float().to(dev()), img.to(dev()),
+                                                      None if stats is None else stats.detach().float().to(dev()),
+                                                      beta, sigmoid=sigmoid, mse_prior=mse_prior, want_recon=True)
+    lo = losses.cpu().double()
+    assert abs(lo[0] - rec.item()) <= 1e-5 * abs(rec.item())
+    assert abs(lo[2] - total.item()) <= 1e-5 * abs(total.item())
+    if variational:
+        assert abs(lo[1] - kl.item()) <= 1e-5 * abs(kl.item())
+        close(dstats, grads[1], name="dstats")
+    close(dpre, grads[0], name="dpre")
+    close(rout, recon, name="recon")
