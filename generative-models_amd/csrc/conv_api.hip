@@ -21,7 +21,7 @@ extern "C" int gmk_conv2d_fwd(const float* x, const float* w, const float* bias,
   int rc = conv_common_checks(N, Cin, H, W, Cout, ksize);
   if (rc) return rc;
   GMK_REQUIRE(stride == 1 || stride == 2, GMK_E_UNSUPPORTED);
-  GMK_REQUIRE(act >= GMK_ACT_NONE && act <= GMK_ACT_MISH, GMK_E_UNSUPPORTED);
+  GMK_REQUIRE(act >= GMK_ACT_NONE && act <= GMK_ACT_SIGMOID, GMK_E_UNSUPPORTED);
   const int KK = ksize * ksize;
   ConvGeom g{};
   g.x = x; g.w = w; g.bias = bias; g.dact_in = nullptr; g.y = y; g.dact_out = dact;
@@ -54,7 +54,7 @@ extern "C" int gmk_deconv2d_fwd(const float* x, const float* w, const float* bia
   int rc = conv_common_checks(N, Cin, H, W, Cout, ksize);
   if (rc) return rc;
   GMK_REQUIRE(W <= 64, GMK_E_SHAPE);
-  GMK_REQUIRE(act >= GMK_ACT_NONE && act <= GMK_ACT_MISH, GMK_E_UNSUPPORTED);
+  GMK_REQUIRE(act >= GMK_ACT_NONE && act <= GMK_ACT_SIGMOID, GMK_E_UNSUPPORTED);
   const int KK = ksize * ksize;
   ConvGeom g{};
   g.x = x; g.w = w; g.bias = bias; g.dact_in = nullptr; g.y = y; g.dact_out = dact;

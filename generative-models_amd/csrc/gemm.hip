@@ -161,7 +161,7 @@ extern "C" int gmk_linear_fwd(const float* x, const float* w, const float* bias,
                               int K, int N, int act, void* ws, size_t ws_bytes, gmk_stream_t stream) {
   GMK_REQUIRE(x && w && y, GMK_E_NULL);
   GMK_REQUIRE(M > 0 && K > 0 && N > 0, GMK_E_SHAPE);
-  GMK_REQUIRE(act >= GMK_ACT_NONE && act <= GMK_ACT_MISH, GMK_E_UNSUPPORTED);
+  GMK_REQUIRE(act >= GMK_ACT_NONE && act <= GMK_ACT_SIGMOID, GMK_E_UNSUPPORTED);
   GemmArgs g{};
   g.A = x; g.B = w; g.C = y; g.bias = bias; g.dact = dact; g.mul = nullptr;
   g.M = M; g.N = N; g.K = K; g.sai = K; g.sak = 1; g.sbk = 1; g.sbj = K; g.ldc = N;

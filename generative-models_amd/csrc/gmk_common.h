@@ -76,6 +76,12 @@ __device__ __forceinline__ void gmk_act_fwd(int act, float z, float& a, float& d
       d = th + z * (1.f - th * th) * s;
       break;
     }
+    case GMK_ACT_SIGMOID: {
+      float s = 1.0f / (1.0f + expf(-z));
+      a = s;
+      d = s * (1.f - s);
+      break;
+    }
     default:
       a = z;
       d = 1.f;

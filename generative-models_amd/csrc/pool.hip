@@ -1,0 +1,180 @@
+// pool.hip -- 2x2 max-pool and x2 upsample (nearest / bilinear / bicubic), forward and backward.
+// Bandwidth-shaped elementwise kernels for the pool/upsample variants of the autoencoder
+// (/root/reference/models/autoencoders.py:40,48,52,89,100,104).  PyTorch semantics:
+// max-pool ties go to the first element in (row, col) scan order; interpolation uses
+// align_corners=False, bicubic with A = -0.75 and border-clamped taps.
+#include "gmk_common.h"
+
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           unsigned char* __restrict__ idx, long long planes, int H, int W) {
+  const int OH = H / 2, OW = W / 2;
+  const long long total = planes * OH * OW;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int ox = (int)(e % OW), oy = (int)((e / OW) % OH);
+    const long long pl = e / ((long long)OW * OH);
+    const float* p = x + (pl * H + 2 * oy) * W + 2 * ox;
+    float best = p[0];
+    int k = 0;
+    float v = p[1];     if (v > best || v != v) { best = v; k = 1; }
+    v = p[W];           if (v > best || v != v) { best = v; k = 2; }
+    v = p[W + 1];       if (v > best || v != v) { best = v; k = 3; }
+    y[e] = best;
+    if (idx) idx[e] = (unsigned char)k;
+  }
+}
+
+// dx (planes,H,W) = scatter of dy (planes,H/2,W/2) to the arg-max, times dact_in (optional)
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                                           const float* __restrict__ dact_in, float* __restrict__ dx,
+                                                           long long planes, int H, int W) {
+  const int OH = H / 2, OW = W / 2;
+  const long long total = planes * OH * OW;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int ox = (int)(e % OW), oy = (int)((e / OW) % OH);
+    const long long pl = e / ((long long)OW * OH);
+    const long long base = (pl * H + 2 * oy) * W + 2 * ox;
+    const float g = dy[e];
+    const int k = idx[e];
+    float v0 = k == 0 ? g : 0.f, v1 = k == 1 ? g : 0.f, v2 = k == 2 ? g : 0.f, v3 = k == 3 ? g : 0.f;
+    if (dact_in) { v0 *= dact_in[base]; v1 *= dact_in[base + 1]; v2 *= dact_in[base + W]; v3 *= dact_in[base + W + 1]; }
+    dx[base] = v0; dx[base + 1] = v1; dx[base + W] = v2; dx[base + W + 1] = v3;
+  }
+}
+
+// ---- x2 interpolation taps (per dimension) ----
+struct Taps { int i[4]; float w[4]; int n; };
+
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+__device__ __forceinline__ Taps up2_taps(int mode, int o, int in) {
+  Taps t;
+  if (mode == GMK_UP_NEAREST) {
+    t.n = 1; t.i[0] = o >> 1; t.w[0] = 1.f;
+  } else if (mode == GMK_UP_BILINEAR) {
+    float src = 0.5f * (o + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    const int i0 = (int)src;
+    const float l = src - i0;
+    t.n = 2; t.i[0] = i0; t.i[1] = i0 + 1 < in ? i0 + 1 : in - 1; t.w[0] = 1.f - l; t.w[1] = l;
+  } else {
+    const float src = 0.5f * (o + 0.5f) - 0.5f;
+    const float fl = floorf(src);
+    const int i0 = (int)fl;
+    const float tt = src - fl;
+    const float A = -0.75f;
+    t.n = 4;
+    t.w[0] = cubic2(tt + 1.f, A); t.w[1] = cubic1(tt, A); t.w[2] = cubic1(1.f - tt, A); t.w[3] = cubic2(2.f - tt, A);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { int ii = i0 - 1 + k; t.i[k] = ii < 0 ? 0 : (ii > in - 1 ? in - 1 : ii); }
+  }
+  return t;
+}
+
+__global__ __launch_bounds__(256) void upsample2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            long long planes, int H, int W, int mode) {
+  const int OH = 2 * H, OW = 2 * W;
+  const long long total = planes * OH * OW;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int ox = (int)(e % OW), oy = (int)((e / OW) % OH);
+    const long long pl = e / ((long long)OW * OH);
+    const float* p = x + pl * H * W;
+    const Taps ty = up2_taps(mode, oy, H), tx = up2_taps(mode, ox, W);
+    float acc = 0.f;
+    for (int a = 0; a < ty.n; ++a) {
+      float row = 0.f;
+      for (int b = 0; b < tx.n; ++b) row += tx.w[b] * p[ty.i[a] * W + tx.i[b]];
+      acc += ty.w[a] * row;
+    }
+    y[e] = acc;
+  }
+}
+
+// weight with which output index o reads input index i (sum over clamped taps)
+__device__ __forceinline__ float up2_weight(int mode, int o, int i, int in) {
+  const Taps t = up2_taps(mode, o, in);
+  float w = 0.f;
+  for (int k = 0; k < t.n; ++k) if (t.i[k] == i) w += t.w[k];
+  return w;
+}
+
+// dx (planes,H,W) = transpose-interpolation of dy (planes,2H,2W), times dact_in (optional)
+__global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dact_in,
+                                                            float* __restrict__ dx, long long planes, int H, int W, int mode) {
+  const int OH = 2 * H, OW = 2 * W;
+  const long long total = planes * H * W;
+  const int R = mode == GMK_UP_NEAREST ? 0 : (mode == GMK_UP_BILINEAR ? 2 : 5);  // reach in output rows/cols
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int ix = (int)(e % W), iy = (int)((e / W) % H);
+    const long long pl = e / ((long long)W * H);
+    const float* g = dy + pl * OH * OW;
+    float acc = 0.f;
+    if (mode == GMK_UP_NEAREST) {
+      const float* q = g + (2 * iy) * OW + 2 * ix;
+      acc = (q[0] + q[1]) + (q[OW] + q[OW + 1]);
+    } else {
+      const int oy0 = max(0, 2 * iy - R), oy1 = min(OH - 1, 2 * iy + 1 + R);
+      const int ox0 = max(0, 2 * ix - R), ox1 = min(OW - 1, 2 * ix + 1 + R);
+      for (int oy = oy0; oy <= oy1; ++oy) {
+        const float wy = up2_weight(mode, oy, iy, H);
+        if (wy == 0.f) continue;
+        float row = 0.f;
+        for (int ox = ox0; ox <= ox1; ++ox) {
+          const float wx = up2_weight(mode, ox, ix, W);
+          if (wx != 0.f) row += wx * g[oy * OW + ox];
+        }
+        acc += wy * row;
+      }
+    }
+    if (dact_in) acc *= dact_in[e];
+    dx[e] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void ew_mul_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     float* __restrict__ out, long long n) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) out[e] = a[e] * b[e];
+}
+
+static inline int blocks_for(long long total) {
+  long long b = (total + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+extern "C" int gmk_maxpool2_fwd(const float* x, float* y, unsigned char* idx, int64_t planes, int H, int W, gmk_stream_t stream) {
+  GMK_REQUIRE(x && y, GMK_E_NULL);
+  GMK_REQUIRE(planes > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, GMK_E_SHAPE);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(blocks_for(planes * (H / 2) * (W / 2))), dim3(256), 0, (hipStream_t)stream, x, y, idx, (long long)planes, H, W);
+  GMK_CHECK_LAUNCH();
+  return GMK_OK;
+}
+extern "C" int gmk_maxpool2_bwd(const float* dy, const unsigned char* idx, const float* dact_in, float* dx, int64_t planes, int H, int W, gmk_stream_t stream) {
+  GMK_REQUIRE(dy && idx && dx, GMK_E_NULL);
+  GMK_REQUIRE(planes > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, GMK_E_SHAPE);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(blocks_for(planes * (H / 2) * (W / 2))), dim3(256), 0, (hipStream_t)stream, dy, idx, dact_in, dx, (long long)planes, H, W);
+  GMK_CHECK_LAUNCH();
+  return GMK_OK;
+}
+extern "C" int gmk_upsample2_fwd(const float* x, float* y, int64_t planes, int H, int W, int mode, gmk_stream_t stream) {
+  GMK_REQUIRE(x && y, GMK_E_NULL);
+  GMK_REQUIRE(planes > 0 && H >= 1 && W >= 1, GMK_E_SHAPE);
+  GMK_REQUIRE(mode >= GMK_UP_NEAREST && mode <= GMK_UP_BICUBIC, GMK_E_UNSUPPORTED);
+  hipLaunchKernelGGL(upsample2_fwd_kernel, dim3(blocks_for(planes * 4 * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, (long long)planes, H, W, mode);
+  GMK_CHECK_LAUNCH();
+  return GMK_OK;
+}
+extern "C" int gmk_upsample2_bwd(const float* dy, const float* dact_in, float* dx, int64_t planes, int H, int W, int mode, gmk_stream_t stream) {
+  GMK_REQUIRE(dy && dx, GMK_E_NULL);
+  GMK_REQUIRE(planes > 0 && H >= 1 && W >= 1, GMK_E_SHAPE);
+  GMK_REQUIRE(mode >= GMK_UP_NEAREST && mode <= GMK_UP_BICUBIC, GMK_E_UNSUPPORTED);
+  hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(blocks_for(planes * H * W)), dim3(256), 0, (hipStream_t)stream, dy, dact_in, dx, (long long)planes, H, W, mode);
+  GMK_CHECK_LAUNCH();
+  return GMK_OK;
+}
+extern "C" int gmk_ew_mul(const float* a, const float* b, float* out, int64_t n, gmk_stream_t stream) {
+  GMK_REQUIRE(a && b && out, GMK_E_NULL);
+  GMK_REQUIRE(n > 0, GMK_E_SHAPE);
+  hipLaunchKernelGGL(ew_mul_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long long)n);
+  GMK_CHECK_LAUNCH();
+  return GMK_OK;
+}

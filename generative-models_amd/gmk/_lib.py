@@ -5,7 +5,9 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libgmk.so")
 
-ACT_IDS = {None: 0, "none": 0, "relu": 1, "leaky-relu": 2, "elu": 3, "selu": 4, "gelu": 5, "swish": 6, "mish": 7}
+ACT_IDS = {None: 0, "none": 0, "relu": 1, "leaky-relu": 2, "elu": 3, "selu": 4, "gelu": 5, "swish": 6, "mish": 7,
+           "sigmoid": 8}
+UPSAMPLE_IDS = {"nearest": 0, "bilinear": 1, "bicubic": 2}
 
 _P = C.c_void_p
 _I = C.c_int
@@ -31,6 +33,11 @@ SIGNATURES = {
     "gmk_linear_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _Z, _P]),
     "gmk_reparam_fwd": (_I, [_P, _P, _P, _L, _L, _P]),
     "gmk_reparam_bwd": (_I, [_P, _P, _P, _P, _L, _L, _I, _P]),
+    "gmk_maxpool2_fwd": (_I, [_P, _P, _P, _L, _I, _I, _P]),
+    "gmk_maxpool2_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),
+    "gmk_upsample2_fwd": (_I, [_P, _P, _L, _I, _I, _I, _P]),
+    "gmk_upsample2_bwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
+    "gmk_ew_mul": (_I, [_P, _P, _P, _L, _P]),
     "gmk_vae_loss_workspace_bytes": (_Z, []),
     "gmk_vae_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _F, _I, _P, _Z, _P]),
 }
@@ -62,6 +69,8 @@ def check(code):
 
 def act_id(act):
     """Map an activation name or an nn.Module instance (utils.get_activation_function) to gmk_act."""
+    if isinstance(act, int):
+        return act
     if act is None or isinstance(act, str):
         return ACT_IDS[act]
     import torch.nn as nn

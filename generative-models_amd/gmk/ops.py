@@ -5,7 +5,7 @@ memory plumbing), and launches on torch's current stream.
 """
 import torch
 
-from ._lib import lib, check, act_id
+from ._lib import lib, check, act_id, UPSAMPLE_IDS
 
 _ws_cache = {}
 
@@ -55,12 +55,17 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, dact_in=None):
     return dx
 
 
-def conv2d_wgrad(dy, x, ksize, stride=1, want_bias=True):
+def conv2d_wgrad(dy, x, ksize, stride=1, want_bias=True, out=None):
+    """out: optional (dw, db) tensors to write into (e.g. views of a flat gradient buffer)."""
     _chk(dy, x)
     N, Cin, H, W = x.shape
     Cout = dy.shape[1]
-    dw = torch.empty((Cout, Cin, ksize, ksize), device=x.device, dtype=torch.float32)
-    db = torch.empty((Cout,), device=x.device, dtype=torch.float32) if want_bias else None
+    if out is not None:
+        dw, db = out
+        _chk(dw, db)
+    else:
+        dw = torch.empty((Cout, Cin, ksize, ksize), device=x.device, dtype=torch.float32)
+        db = torch.empty((Cout,), device=x.device, dtype=torch.float32) if want_bias else None
     nb = lib().gmk_conv2d_wgrad_workspace_bytes(N, Cin, H, W, Cout, ksize, stride)
     ws = workspace(nb, x.device)
     check(lib().gmk_conv2d_wgrad(_p(dy), _p(x), _p(dw), _p(db), N, Cin, H, W, Cout, ksize, stride, _p(ws), ws.numel(), _stream()))
@@ -86,12 +91,16 @@ def deconv2d_dgrad(dy, w, x_shape, dact_in=None):
     return dx
 
 
-def deconv2d_wgrad(dy, x, ksize, want_bias=True):
+def deconv2d_wgrad(dy, x, ksize, want_bias=True, out=None):
     _chk(dy, x)
     N, Cin, H, W = x.shape
     Cout = dy.shape[1]
-    dw = torch.empty((Cin, Cout, ksize, ksize), device=x.device, dtype=torch.float32)
-    db = torch.empty((Cout,), device=x.device, dtype=torch.float32) if want_bias else None
+    if out is not None:
+        dw, db = out
+        _chk(dw, db)
+    else:
+        dw = torch.empty((Cin, Cout, ksize, ksize), device=x.device, dtype=torch.float32)
+        db = torch.empty((Cout,), device=x.device, dtype=torch.float32) if want_bias else None
     nb = lib().gmk_deconv2d_wgrad_workspace_bytes(N, Cin, H, W, Cout, ksize)
     ws = workspace(nb, x.device)
     check(lib().gmk_deconv2d_wgrad(_p(dy), _p(x), _p(dw), _p(db), N, Cin, H, W, Cout, ksize, _p(ws), ws.numel(), _stream()))
@@ -119,12 +128,16 @@ def linear_dgrad(dy, w, dact_in=None):
     return dx
 
 
-def linear_wgrad(dy, x, want_bias=True):
+def linear_wgrad(dy, x, want_bias=True, out=None):
     _chk(dy, x)
     M, N = dy.shape
     K = x.shape[1]
-    dw = torch.empty((N, K), device=x.device, dtype=torch.float32)
-    db = torch.empty((N,), device=x.device, dtype=torch.float32) if want_bias else None
+    if out is not None:
+        dw, db = out
+        _chk(dw, db)
+    else:
+        dw = torch.empty((N, K), device=x.device, dtype=torch.float32)
+        db = torch.empty((N,), device=x.device, dtype=torch.float32) if want_bias else None
     ws = workspace(lib().gmk_linear_workspace_bytes(M, K, N), x.device)
     check(lib().gmk_linear_wgrad(_p(dy), _p(x), _p(dw), _p(db), M, K, N, _p(ws), ws.numel(), _stream()))
     return dw, db
@@ -167,3 +180,45 @@ def vae_loss_fwd_bwd(pre, image, stats, beta, sigmoid=True, mse_prior=False, wan
     check(lib().gmk_vae_loss_fwd_bwd(_p(pre), _p(image), _p(stats), _p(recon), _p(dpre), _p(dstats), _p(losses),
                                      B, chw, L, float(beta), flags, _p(ws), ws.numel(), _stream()))
     return losses, dpre, dstats, recon
+
+
+def maxpool2_fwd(x, want_idx=True):
+    _chk(x)
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, H // 2, W // 2), device=x.device, dtype=torch.float32)
+    idx = torch.empty((N, C, H // 2, W // 2), device=x.device, dtype=torch.uint8) if want_idx else None
+    check(lib().gmk_maxpool2_fwd(_p(x), _p(y), _p(idx), N * C, H, W, _stream()))
+    return (y, idx) if want_idx else y
+
+
+def maxpool2_bwd(dy, idx, dact_in=None):
+    _chk(dy, dact_in)
+    N, C, OH, OW = dy.shape
+    dx = torch.empty((N, C, 2 * OH, 2 * OW), device=dy.device, dtype=torch.float32)
+    check(lib().gmk_maxpool2_bwd(_p(dy), _p(idx), _p(dact_in), _p(dx), N * C, 2 * OH, 2 * OW, _stream()))
+    return dx
+
+
+def upsample2_fwd(x, mode="nearest"):
+    _chk(x)
+    if mode not in UPSAMPLE_IDS:
+        raise NotImplementedError(f"interpolation mode {mode!r} is not valid for 4-D input (nearest|bilinear|bicubic)")
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+    check(lib().gmk_upsample2_fwd(_p(x), _p(y), N * C, H, W, UPSAMPLE_IDS[mode], _stream()))
+    return y
+
+
+def upsample2_bwd(dy, mode="nearest", dact_in=None):
+    _chk(dy, dact_in)
+    N, C, OH, OW = dy.shape
+    dx = torch.empty((N, C, OH // 2, OW // 2), device=dy.device, dtype=torch.float32)
+    check(lib().gmk_upsample2_bwd(_p(dy), _p(dact_in), _p(dx), N * C, OH // 2, OW // 2, UPSAMPLE_IDS[mode], _stream()))
+    return dx
+
+
+def ew_mul(a, b):
+    _chk(a, b)
+    out = torch.empty_like(a)
+    check(lib().gmk_ew_mul(_p(a), _p(b), _p(out), a.numel(), _stream()))
+    return out

@@ -1,0 +1,267 @@
+"""Encoder / Decoder / Autoencoder with the reference's Python surface on libgmk kernels.
+
+Mirrors /root/reference/models/autoencoders.py: same class names and module path (full-model
+pickles resolve `models.autoencoders.Autoencoder`), same constructor arguments, same child
+modules and parameter names/shapes (state_dicts are interchangeable), same side-channel
+attributes (`.stats`, `.normal`, `.latent_vector`) and `.sample()`.
+
+nn.Conv2d / nn.ConvTranspose2d / nn.Linear children are kept as *parameter containers* (their
+default initialisation is therefore bit-identical to the reference under the same seed); their
+forward is never called: all arithmetic runs in hand-written gfx950 kernels (gmk/engine.py).
+There is no PyTorch fallback: CPU tensors or a missing libgmk.so raise.
+
+Besides the drop-in autograd path (`recon = model(image)` then any loss), `train_step()` runs the
+whole step (forward, fused sigmoid+MSE+KL loss kernel, backward) without autograd bookkeeping.
+"""
+import torch
+import torch.nn as nn
+
+from gmk import engine, ops, act_id
+from utils import print_debug
+
+
+def _local_params(module):
+    return {n: p for n, p in module.named_parameters()}
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, x, names, train, *params):
+        p = dict(zip(names, params))
+        out, sv = engine.encoder_forward(p, x.contiguous(), act=mod._act_id, no_pool=mod.no_pool,
+                                         ksize=mod.kernel_size, train=train)
+        ctx.mod, ctx.names, ctx.p, ctx.sv = mod, names, p, sv
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mod = ctx.mod
+        g = engine.encoder_backward(ctx.p, ctx.sv, dout.contiguous(), no_pool=mod.no_pool, ksize=mod.kernel_size)
+        ctx.sv = None
+        return (None, None, None, None) + tuple(g[n] for n in ctx.names)
+
+
+class _DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, z, names, train, *params):
+        p = dict(zip(names, params))
+        out, sv = engine.decoder_forward(p, z.contiguous(), act=mod._act_id, num_channels=mod.num_channels,
+                                         no_upsample=mod.no_upsample, interpolation=mod.interpolation,
+                                         ksize=mod.kernel_size, base=mod.base, train=train,
+                                         final_act="sigmoid" if mod.use_sigmoid else None)
+        ctx.mod, ctx.names, ctx.p, ctx.sv = mod, names, p, sv
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mod = ctx.mod
+        dpre = dout.contiguous()
+        if mod.use_sigmoid:
+            dpre = ops.ew_mul(dpre, ctx.sv["e5"])
+        g, dz = engine.decoder_backward(ctx.p, ctx.sv, dpre, no_upsample=mod.no_upsample,
+                                        interpolation=mod.interpolation, ksize=mod.kernel_size,
+                                        need_dz=ctx.needs_input_grad[1])
+        ctx.sv = None
+        return (None, dz, None, None) + tuple(g[n] for n in ctx.names)
+
+
+class _ReparamFn(torch.autograd.Function):
+    """z = mu + exp(0.5*log_var) * eps on the interleaved (B,L,2) stats (autoencoders.py:169-176)."""
+    @staticmethod
+    def forward(ctx, stats, eps):
+        stats = stats.contiguous()
+        ctx.save_for_backward(stats, eps)
+        return ops.reparam_fwd(stats, eps)
+
+    @staticmethod
+    def backward(ctx, dz):
+        stats, eps = ctx.saved_tensors
+        return ops.reparam_bwd(dz.contiguous(), stats, eps), None
+
+
+def _padding(kernel_size):
+    if kernel_size == 3:
+        return 1
+    if kernel_size == 5:
+        return 2
+    print(f'\n\nkernel_size {kernel_size} is not supported\n\n')  # reference: autoencoders.py:31-32
+    raise NotImplementedError(f'kernel_size {kernel_size} is not supported')
+
+
+class Encoder(nn.Module):
+    def __init__(self, variational=False, latent_size=None, num_channels=None, kernel_size=None, act=None,
+                 no_pool=False, debug=False, base=8) -> None:
+        super().__init__()
+        self.debug = debug
+        self.variational = variational
+        mult = 2 if variational else 1
+        self.latent_size = latent_size
+        self.no_pool = no_pool
+        self.num_channels = num_channels
+        self.kernel_size = kernel_size
+        self.base = base  # spatial size after two /2 stages (reference hard-codes 8, autoencoders.py:41)
+        padding = _padding(kernel_size)
+        C = num_channels
+        self.conv1 = nn.Conv2d(3, C, kernel_size, stride=1, padding=padding)
+        self.conv2 = nn.Conv2d(C, C, kernel_size, stride=1, padding=padding)
+        self.conv3 = nn.Conv2d(C, C, kernel_size, stride=1, padding=padding)
+        if self.no_pool:
+            self.downsample1 = nn.Conv2d(C, C, kernel_size, stride=2, padding=padding)
+            self.downsample2 = nn.Conv2d(C, C, kernel_size, stride=2, padding=padding)
+        else:
+            self.max_pool = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.fc = nn.Linear(in_features=base * base * C, out_features=mult * latent_size)
+        self.act = act
+
+    @property
+    def _act_id(self):
+        return act_id(self.act)
+
+    def forward(self, x):  # input x is (bs, 3, 32, 32) for cifar images
+        print_debug(x, self.debug, name='\nEncoder: input')
+        if x.shape[-1] != 4 * self.base or x.shape[-2] != 4 * self.base:
+            raise RuntimeError(f'Encoder built for {4 * self.base}x{4 * self.base} inputs, got {tuple(x.shape)}')
+        lp = _local_params(self)
+        names = tuple(lp.keys())
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in lp.values())
+        x = _EncoderFn.apply(self, x, names, train, *lp.values())
+        print_debug(x, self.debug, name='Encoder: after fc')
+        if self.variational:
+            out = x.view(x.shape[0], self.latent_size, 2)
+        else:
+            out = x
+        return out
+
+
+class Decoder(nn.Module):
+    def __init__(self, latent_size, num_channels=None, kernel_size=None, act=None, sigmoid=None,
+                 interpolation='bilinear', no_upsample=False, debug=False, base=8) -> None:
+        super().__init__()
+        self.debug = debug
+        self.num_channels = num_channels
+        self.use_sigmoid = sigmoid
+        self.no_upsample = no_upsample
+        self.kernel_size = kernel_size
+        self.interpolation = interpolation
+        self.base = base
+        padding = _padding(kernel_size)
+        C = num_channels
+        self.fc = nn.Linear(in_features=latent_size, out_features=C * base * base)
+        self.conv1 = nn.Conv2d(C, C, kernel_size, stride=1, padding=padding)
+        self.conv2 = nn.Conv2d(C, C, kernel_size, stride=1, padding=padding)
+        self.conv3 = nn.Conv2d(C, 3, kernel_size, stride=1, padding=padding)
+        if self.no_upsample:
+            self.deconv1 = nn.ConvTranspose2d(C, C, kernel_size, stride=2, padding=padding, output_padding=1)
+            self.deconv2 = nn.ConvTranspose2d(C, C, kernel_size, stride=2, padding=padding, output_padding=1)
+        else:
+            self.upsample = nn.Upsample(scale_factor=2, mode=interpolation)
+        self.act = act
+        self.sigmoid = nn.Sigmoid()
+
+    @property
+    def _act_id(self):
+        return act_id(self.act)
+
+    def forward(self, x):  # x shape: (bs, latent_size)
+        print_debug(x, self.debug, name='Decoder: input')
+        lp = _local_params(self)
+        names = tuple(lp.keys())
+        train = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in lp.values()))
+        out = _DecoderFn.apply(self, x, names, train, *lp.values())
+        print_debug(out, self.debug, name='Decoder: after sigmoid')
+        return out
+
+
+class Autoencoder(nn.Module):
+    def __init__(
+        self,
+        variational=False,
+        latent_size=256,
+        num_channels=64,
+        kernel_size=3,
+        act=nn.ReLU,
+        sigmoid=True,
+        interpolation='bilinear',
+        no_pool=False,
+        no_upsample=False,
+        device=None,
+        debug=False,
+        image_size=32,
+    ) -> None:
+        super().__init__()
+        base = image_size // 4  # reference: 8 (32x32 CIFAR); config 5 uses 64x64 -> 16
+        self.encoder = Encoder(variational=variational, latent_size=latent_size, num_channels=num_channels,
+                               kernel_size=kernel_size, act=act, no_pool=no_pool, debug=debug, base=base)
+        self.decoder = Decoder(latent_size, num_channels=num_channels, kernel_size=kernel_size, act=act,
+                               sigmoid=sigmoid, interpolation=interpolation, no_upsample=no_upsample,
+                               debug=debug, base=base)
+        self.variational = variational
+        self.latent_size = latent_size
+        self.sigmoid = nn.Sigmoid()
+        self.device = device
+
+    def forward(self, x):
+        out = self.encoder(x)
+        if self.variational:
+            self.stats = out
+            means = self.stats[:, :, 0]
+            # reparametrization trick: sample a value as mean + std * N(0, 1)
+            self.normal = torch.randn_like(means).contiguous()
+            self.latent_vector = _ReparamFn.apply(self.stats, self.normal)  # (num_images, latent)
+        else:
+            self.latent_vector = out
+        return self.decoder(self.latent_vector)
+
+    def sample(self, name=None, num_images=8, return_samples=False):
+        self.eval()
+        latent_vector = torch.randn(size=(num_images, self.latent_size), device=self.device)
+        out = self.decoder(latent_vector)
+        if return_samples:
+            return out
+        from utils import save_image_grid
+        save_image_grid(out.detach().cpu(), f'plots/samples_{name}.png', nrow=4, figsize=(7, 4.5))
+
+    # ------------------------------------------------------------------ fused train step
+    def train_step(self, image, beta=0.0, mse_prior=False, eps=None):
+        """Forward + fused loss + backward of /root/reference/main.py:29-51 without autograd.
+
+        Overwrites `.grad` of every parameter (what zero_grad + backward leave behind) and returns a
+        device tensor [rec, kl, total] (kl unweighted, total = rec + beta*kl).  The optimizer step
+        stays with the caller (main.py:52-53).  `eps` replaces torch.randn for parity tests.
+        """
+        if not self.decoder.use_sigmoid:
+            sigmoid = False
+        else:
+            sigmoid = True
+        enc, dec = self.encoder, self.decoder
+        pe = {n: p.data for n, p in enc.named_parameters()}
+        pd = {n: p.data for n, p in dec.named_parameters()}
+        for p in self.parameters():
+            if p.grad is None:
+                p.grad = torch.empty_like(p.data)
+        ge = {n: p.grad for n, p in enc.named_parameters()}
+        gd = {n: p.grad for n, p in dec.named_parameters()}
+        image = image.contiguous()
+        B = image.shape[0]
+        out, sve = engine.encoder_forward(pe, image, act=enc._act_id, no_pool=enc.no_pool, ksize=enc.kernel_size, train=True)
+        if self.variational:
+            stats = out.view(B, self.latent_size, 2)
+            if eps is None:
+                eps = torch.randn((B, self.latent_size), device=image.device, dtype=torch.float32)
+            z = ops.reparam_fwd(stats, eps)
+            self.stats, self.normal = stats, eps
+        else:
+            stats, z = None, out
+        self.latent_vector = z
+        pre, svd = engine.decoder_forward(pd, z, act=dec._act_id, num_channels=dec.num_channels,
+                                          no_upsample=dec.no_upsample, interpolation=dec.interpolation,
+                                          ksize=dec.kernel_size, base=dec.base, train=True, final_act=None)
+        losses, dpre, dstats, _ = ops.vae_loss_fwd_bwd(pre, image, stats, beta, sigmoid=sigmoid, mse_prior=mse_prior)
+        _, dz = engine.decoder_backward(pd, svd, dpre, no_upsample=dec.no_upsample, interpolation=dec.interpolation,
+                                        ksize=dec.kernel_size, need_dz=True, gout=gd)
+        if self.variational:
+            dout = ops.reparam_bwd(dz, stats, eps, dstats=dstats).view(B, -1)
+        else:
+            dout = dz
+        engine.encoder_backward(pe, sve, dout, no_pool=enc.no_pool, ksize=enc.kernel_size, gout=ge)
+        return losses

@@ -45,7 +45,8 @@ enum gmk_act {
   GMK_ACT_SELU = 4,
   GMK_ACT_GELU = 5,
   GMK_ACT_SILU = 6,
-  GMK_ACT_MISH = 7
+  GMK_ACT_MISH = 7,
+  GMK_ACT_SIGMOID = 8 /* models/autoencoders.py:109-110 (decoder output) */
 };
 
 int gmk_version(void);
@@ -129,6 +130,24 @@ int gmk_vae_loss_fwd_bwd(const float* pre, const float* image, const float* stat
                          float* recon_out, float* dpre, float* dstats, float* losses,
                          int64_t B, int64_t chw, int64_t L, float beta, int flags,
                          void* ws, size_t ws_bytes, gmk_stream_t stream);
+
+/* ---------------------------------------------------------------- pool / upsample -------
+ * Pool + upsample variants of the autoencoder (models/autoencoders.py:40,48,52,89,100,104).
+ * `planes` = N*C.  maxpool: (planes,H,W) -> (planes,H/2,W/2), idx (uint8, 0..3) records the
+ * arg-max for the backward pass (first maximum in scan order, like PyTorch).
+ * upsample x2: nn.Upsample(scale_factor=2, mode) with align_corners=False.
+ * The *_bwd kernels multiply by dact_in (act' of the producing layer) when it is not NULL. */
+enum gmk_upsample_mode { GMK_UP_NEAREST = 0, GMK_UP_BILINEAR = 1, GMK_UP_BICUBIC = 2 };
+int gmk_maxpool2_fwd(const float* x, float* y, unsigned char* idx, int64_t planes, int H, int W,
+                     gmk_stream_t stream);
+int gmk_maxpool2_bwd(const float* dy, const unsigned char* idx, const float* dact_in, float* dx,
+                     int64_t planes, int H, int W, gmk_stream_t stream);
+int gmk_upsample2_fwd(const float* x, float* y, int64_t planes, int H, int W, int mode,
+                      gmk_stream_t stream);
+int gmk_upsample2_bwd(const float* dy, const float* dact_in, float* dx, int64_t planes, int H, int W,
+                      int mode, gmk_stream_t stream);
+/* out = a * b elementwise (autograd glue: d_pre = d_recon * sigmoid') */
+int gmk_ew_mul(const float* a, const float* b, float* out, int64_t n, gmk_stream_t stream);
 
 #ifdef __cplusplus
 }

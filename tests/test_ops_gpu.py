@@ -197,3 +197,38 @@ def test_vae_loss_fwd_bwd(B, sigmoid, variational, mse_prior):
         close(dstats, grads[1], name="dstats")
     close(dpre, grads[0], name="dpre")
     close(rout, recon, name="recon")
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 16, 16), (3, 5, 32, 32), (1, 4, 8, 8)])
+def test_maxpool2(shape):
+    from gmk import ops
+    x = T(f"mp{shape}", shape).double().requires_grad_(True)
+    y = F.max_pool2d(x, 2, 2)
+    dy = T(f"mpd{shape}", tuple(y.shape))
+    (gx,) = torch.autograd.grad(y, x, dy.double())
+    dact = T(f"mpa{shape}", shape, 0, 1)
+    yg, idx = ops.maxpool2_fwd(x.detach().float().to(dev()))
+    close(yg, y, name="y")
+    dx = ops.maxpool2_bwd(dy.to(dev()), idx, dact_in=dact.to(dev()))
+    close(dx, gx * dact.double(), name="dx")
+    # ties (post-ReLU zeros): gradient goes to the first element in scan order, like PyTorch
+    xz = torch.zeros(1, 1, 4, 4).requires_grad_(True)
+    yz = F.max_pool2d(xz, 2, 2)
+    (gz,) = torch.autograd.grad(yz, xz, torch.ones_like(yz))
+    _, idz = ops.maxpool2_fwd(xz.detach().to(dev()))
+    dz = ops.maxpool2_bwd(torch.ones(1, 1, 2, 2, device=dev()), idz)
+    close(dz, gz, name="tie")
+
+
+@pytest.mark.parametrize("mode", ["nearest", "bilinear", "bicubic"])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 8), (1, 3, 16, 16), (2, 2, 4, 4)])
+def test_upsample2(mode, shape):
+    from gmk import ops
+    x = T(f"up{shape}", shape).double().requires_grad_(True)
+    y = F.interpolate(x, scale_factor=2, mode=mode)
+    dy = T(f"upd{shape}", tuple(y.shape))
+    (gx,) = torch.autograd.grad(y, x, dy.double())
+    dact = T(f"upa{shape}", shape, 0, 1)
+    close(ops.upsample2_fwd(x.detach().float().to(dev()), mode), y, name="y")
+    close(ops.upsample2_bwd(dy.to(dev()), mode, dact_in=dact.to(dev())), gx * dact.double(), name="dx")
+    close(ops.upsample2_bwd(dy.to(dev()), mode), gx, name="dx(no dact)")
