@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py -- train images/sec of the CIFAR-10 VAE train step (BASELINE.json configs[1]/[2]) on
+N MI355X GPUs of one node, plus FID-stats samples/sec, the dominant kernel's roofline fraction and
+a same-run CPU baseline.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = forward + fused sigmoid/MSE/KL loss kernel + backward + bucketed gradient all-reduce
+(RCCL, overlapped with backward) + fused AdamW + cosine LR step, i.e. main.py:27-53 of the
+reference, on a device-resident synthetic batch of 256 images per GPU (weak scaling).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "generative-models_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+TRAIN_MFLOP_PER_IMG = 319.68      # algorithmic FLOPs of one VAE-256 train step per image
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix peak
+PER_GPU_BATCH = 256
+
+
+def build(device):
+    from models.autoencoders import Autoencoder
+    from utils import get_activation_function
+    from gmk.optim import FusedAdamW
+    torch.manual_seed(0)
+    model = Autoencoder(variational=True, latent_size=256, num_channels=64, kernel_size=3,
+                        act=get_activation_function("gelu"), sigmoid=True, interpolation="nearest",
+                        no_pool=True, no_upsample=True, device=device).to(device)
+    optim = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(optim, T_max=100 * 196)
+    return model, optim, sched
+
+
+def dominant_kernel_roofline(device, iters=30):
+    """Times the heaviest kernel class of the step alone: conv_igemm_kernel on the 64->64 3x3 conv at
+    16x16 (enc.conv2 / dec.conv2 shape, B=256) with HIP events on the launch stream."""
+    from gmk import ops
+    N, C, H = PER_GPU_BATCH, 64, 16
+    x = torch.rand(N, C, H, H, device=device)
+    w = (torch.rand(C, C, 3, 3, device=device) - 0.5) * 0.1
+    b = torch.zeros(C, device=device)
+    for _ in range(5):
+        ops.conv2d_fwd(x, w, b, act="gelu", want_dact=True)
+    torch.cuda.synchronize()
+    s = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(iters):
+        ops.conv2d_fwd(x, w, b, act="gelu", want_dact=True)
+    e1.record(s)
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / iters
+    flops = 2.0 * N * H * H * C * C * 9
+    ach = flops / t / 1e12
+    return {"kernel": "conv_igemm_kernel<S1,k3,64->64,16x16,B256>", "bound": "mfma", "achieved": round(ach, 2),
+            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            "launch_us": round(t * 1e6, 2), "flops_per_launch": flops, "traffic": None}
+
+
+def cpu_baseline(steps=6):
+    """The oracle (CPU restatement of the reference step incl. AdamW) on this box's host cores."""
+    from oracle import ae_oracle
+    import torch.nn.functional as F  # noqa: F401
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(cores)
+    from models.autoencoders import Autoencoder
+    from utils import get_activation_function
+    torch.manual_seed(0)
+    m = Autoencoder(variational=True, latent_size=256, num_channels=64, kernel_size=3,
+                    act=get_activation_function("gelu"), sigmoid=True, no_pool=True, no_upsample=True)
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    opt = torch.optim.AdamW(list(params.values()), lr=1e-3, weight_decay=0.01)
+    cfg = dict(variational=True, latent_size=256, num_channels=64, act="gelu", sigmoid=True,
+               no_pool=True, no_upsample=True)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand(PER_GPU_BATCH, 3, 32, 32, generator=g)
+
+    def step():
+        eps = torch.randn(PER_GPU_BATCH, 256)
+        recon, stats, z = ae_oracle.autoencoder_forward(params, x, eps, **cfg)
+        rec, kl, total = ae_oracle.train_losses(recon, x, stats, 5e-6, variational=True)
+        opt.zero_grad()
+        total.backward()
+        opt.step()
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(PER_GPU_BATCH / dt, 1), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{steps} train steps of batch {PER_GPU_BATCH} (oracle/ae_oracle.py, torch CPU fp32, same VAE config)",
+            "ms_per_step": round(dt * 1e3, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-fid", action="store_true", help="skip the FID-stats leg")
+    args = ap.parse_args()
+
+    from gmk.parallel import init_from_env, GradReducer
+    rank, local, world = init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    device = torch.device("cuda", local)
+    import gmk
+    gmk.lib()
+
+    model, optim, sched = build(device)
+    if world > 1:  # identical replicas: broadcast rank 0's parameters
+        dist.broadcast(optim.flat_param, src=0)
+    reducer = GradReducer(model, optim)
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    batches = [torch.rand(PER_GPU_BATCH, 3, 32, 32, device=device, generator=gen) for _ in range(4)]
+    egen = torch.Generator(device=device).manual_seed(4321 + rank)
+    beta = 5e-6
+
+    def step(i):
+        eps = torch.randn(PER_GPU_BATCH, 256, device=device, generator=egen)
+        losses = model.train_step(batches[i % len(batches)], beta=beta, eps=eps, reducer=reducer)
+        reducer.wait()
+        optim.step()
+        sched.step()
+        return losses
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_losses = [float(v) for v in losses.cpu()]
+
+    out = None
+    if rank == 0:
+        ips = world * PER_GPU_BATCH * args.steps / dt
+        out = {
+            "metric": "train images/sec (CIFAR-10 VAE)", "value": round(ips, 1), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "VAE latent_size=256 --variational --beta 5e-6 --no_upsample --no_pool, act gelu, "
+                                   "3x32x32, batch 256 per GPU, AdamW+cosine (BASELINE.json configs[1]; configs[2] at N=8)",
+                       "global_batch": world * PER_GPU_BATCH, "parallelism": f"dp{world}"},
+            "final_losses": {"rec": final_losses[0], "kl": final_losses[1], "total": final_losses[2]},
+            "step_mfma_frac": round(ips / world * TRAIN_MFLOP_PER_IMG * 1e6 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+        }
+        out["roofline"] = dominant_kernel_roofline(device)
+    if not args.no_fid:
+        try:
+            from bench_fid import fid_stats_leg
+            fid = fid_stats_leg(device, rank, world)
+            if rank == 0:
+                out["fid_stats"] = fid
+        except ImportError:
+            pass
+    if rank == 0:
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -38,6 +38,7 @@ SIGNATURES = {
     "gmk_upsample2_fwd": (_I, [_P, _P, _L, _I, _I, _I, _P]),
     "gmk_upsample2_bwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
     "gmk_ew_mul": (_I, [_P, _P, _P, _L, _P]),
+    "gmk_adamw_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P]),
     "gmk_vae_loss_workspace_bytes": (_Z, []),
     "gmk_vae_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _F, _I, _P, _Z, _P]),
 }

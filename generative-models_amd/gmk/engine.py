@@ -54,13 +54,15 @@ def encoder_forward(p, x, *, act, no_pool, ksize, train):
     return out, sv
 
 
-def encoder_backward(p, sv, dout, *, no_pool, ksize, gout=None):
+def encoder_backward(p, sv, dout, *, no_pool, ksize, gout=None, on_fc_done=None):
     """dout: (B, mult*L) gradient of the encoder output.  Returns param grads."""
     g = {}
     B = dout.shape[0]
     x = sv["x"]
     a5 = sv["a5"]
     g["fc.weight"], g["fc.bias"] = ops.linear_wgrad(dout, a5.view(B, -1), out=_o(gout, "fc"))
+    if on_fc_done is not None:
+        on_fc_done()  # fc gradients are enqueued: their all-reduce can start under the conv backward
     dz5 = ops.linear_dgrad(dout, p["fc.weight"], dact_in=sv["d5"].view(B, -1)).view_as(a5)
     g["conv3.weight"], g["conv3.bias"] = ops.conv2d_wgrad(dz5, sv["a4"], ksize, 1, out=_o(gout, "conv3"))
     if no_pool:

@@ -222,12 +222,14 @@ class Autoencoder(nn.Module):
         save_image_grid(out.detach().cpu(), f'plots/samples_{name}.png', nrow=4, figsize=(7, 4.5))
 
     # ------------------------------------------------------------------ fused train step
-    def train_step(self, image, beta=0.0, mse_prior=False, eps=None):
+    def train_step(self, image, beta=0.0, mse_prior=False, eps=None, reducer=None):
         """Forward + fused loss + backward of /root/reference/main.py:29-51 without autograd.
 
         Overwrites `.grad` of every parameter (what zero_grad + backward leave behind) and returns a
         device tensor [rec, kl, total] (kl unweighted, total = rec + beta*kl).  The optimizer step
         stays with the caller (main.py:52-53).  `eps` replaces torch.randn for parity tests.
+        `reducer` (gmk.parallel.GradReducer) is told as soon as each gradient bucket is enqueued so
+        that its all-reduce overlaps the rest of backward.
         """
         if not self.decoder.use_sigmoid:
             sigmoid = False
@@ -259,9 +261,14 @@ class Autoencoder(nn.Module):
         losses, dpre, dstats, _ = ops.vae_loss_fwd_bwd(pre, image, stats, beta, sigmoid=sigmoid, mse_prior=mse_prior)
         _, dz = engine.decoder_backward(pd, svd, dpre, no_upsample=dec.no_upsample, interpolation=dec.interpolation,
                                         ksize=dec.kernel_size, need_dz=True, gout=gd)
+        if reducer is not None:
+            reducer.ready("decoder")
         if self.variational:
             dout = ops.reparam_bwd(dz, stats, eps, dstats=dstats).view(B, -1)
         else:
             dout = dz
-        engine.encoder_backward(pe, sve, dout, no_pool=enc.no_pool, ksize=enc.kernel_size, gout=ge)
+        engine.encoder_backward(pe, sve, dout, no_pool=enc.no_pool, ksize=enc.kernel_size, gout=ge,
+                                on_fc_done=(lambda: reducer.ready("encoder.fc")) if reducer is not None else None)
+        if reducer is not None:
+            reducer.ready("encoder.conv")
         return losses

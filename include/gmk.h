@@ -149,6 +149,15 @@ int gmk_upsample2_bwd(const float* dy, const float* dact_in, float* dx, int64_t 
 /* out = a * b elementwise (autograd glue: d_pre = d_recon * sigmoid') */
 int gmk_ew_mul(const float* a, const float* b, float* out, int64_t n, gmk_stream_t stream);
 
+/* ---------------------------------------------------------------- optimizer -------------
+ * gmk_adamw_step: one launch over a flat buffer holding every parameter (n % 4 == 0, padded):
+ *   torch.optim.AdamW(lr, betas, eps, weight_decay) single step, `step` = 1-based step index;
+ *   the gradient is multiplied by gscale first (1/world_size after a SUM all-reduce).
+ *   replaces optim.step(), /root/reference/main.py:52,214. */
+int gmk_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int64_t step, float gscale,
+                   gmk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
