@@ -29,6 +29,7 @@ extern "C" int gmk_conv2d_fwd(const float* x, const float* w, const float* bias,
   g.BW = g.OW; g.lgBW = gmk_ilog2(g.BW); g.lgBHW = gmk_ilog2((int64_t)g.OH * g.OW);
   g.total_base = (long long)N * g.OH * g.OW;
   g.w_layout = 0; g.w_m_stride = Cin * KK; g.w_c_stride = KK; g.flip = 0; g.act = act; g.epi = 0;
+  g.w_numel = Cout * Cin * KK;
   return dispatch(g, ksize, stride == 1 ? 0 : 1, (hipStream_t)stream);
 }
 
@@ -45,6 +46,7 @@ extern "C" int gmk_conv2d_dgrad(const float* dy, const float* w, const float* da
   g.BW = W / stride; g.lgBW = gmk_ilog2(g.BW); g.lgBHW = gmk_ilog2((int64_t)g.IH * g.IW);
   g.total_base = (long long)N * g.IH * g.IW;
   g.w_layout = 1; g.w_m_stride = KK; g.w_c_stride = Cin * KK; g.flip = stride == 1 ? 1 : 0; g.act = 0; g.epi = 1;
+  g.w_numel = Cout * Cin * KK;
   return dispatch(g, ksize, stride == 1 ? 0 : 2, (hipStream_t)stream);
 }
 
@@ -62,6 +64,7 @@ extern "C" int gmk_deconv2d_fwd(const float* x, const float* w, const float* bia
   g.BW = W; g.lgBW = gmk_ilog2(W); g.lgBHW = gmk_ilog2((int64_t)H * W);
   g.total_base = (long long)N * H * W;
   g.w_layout = 1; g.w_m_stride = KK; g.w_c_stride = Cout * KK; g.flip = 0; g.act = act; g.epi = 0;
+  g.w_numel = Cout * Cin * KK;
   return dispatch(g, ksize, 2, (hipStream_t)stream);
 }
 
@@ -78,5 +81,6 @@ extern "C" int gmk_deconv2d_dgrad(const float* dy, const float* w, const float* 
   g.BW = W; g.lgBW = gmk_ilog2(W); g.lgBHW = gmk_ilog2((int64_t)H * W);
   g.total_base = (long long)N * H * W;
   g.w_layout = 0; g.w_m_stride = Cout * KK; g.w_c_stride = KK; g.flip = 0; g.act = 0; g.epi = 1;
+  g.w_numel = Cout * Cin * KK;
   return dispatch(g, ksize, 1, (hipStream_t)stream);
 }

@@ -25,15 +25,20 @@ struct ConvGeom {
   int BW, lgBW, lgBHW;
   long long total_base;
   int w_layout;  // 0: weights addressed [m][c][t] (c,t contiguous per m); 1: [c][m][t]
-  int w_m_stride, w_c_stride, flip;
+  int w_m_stride, w_c_stride, flip, w_numel;
   int act, epi;  // epi 0: +bias, act (and act' to dact_out); 1: * dact_in (dgrad)
   int seg_px, lg_seg_px, nseg;
   int PR, PC, PS, npos;
 };
 
 #define CONV_MAXSLOT 4
+// slot-count instantiations per mode: stride-2 patches are ~4x larger than the tile
+#define GMK_NS_LO(MODE_) ((MODE_) == 1 ? 2 : 1)
+#define GMK_NS_HI(MODE_) ((MODE_) == 1 ? 4 : 2)
 
-template <int MODE, int KS, int CK, int WM, int MT>
+// NSLOT = ceil(npos / 256): patch positions handled per thread (compile time so that the
+// prefetch registers are allocated exactly).
+template <int MODE, int KS, int CK, int WM, int MT, int NSLOT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
   constexpr int WP = 4 / WM, PT = WP * 32, MB = WM * MT * 32, KK = KS * KS, KC = CK * KK, WS = KC | 1;
   constexpr int PAD = (KS - 1) / 2;
@@ -41,6 +46,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
   constexpr int SB = (MODE == 1) ? 2 : 1;
   constexpr int TLO = (MODE == 2) ? (KS - 1 - PAD) / 2 : 0;
   constexpr int ORG = (MODE == 2) ? TLO : PAD;  // patch origin offset (rows/cols before the base position)
+  constexpr int NW = (MB * KC + 255) / 256;     // weight elements staged per thread and chunk
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Wl = smem;
   float* Xl = smem + MB * WS;
@@ -55,12 +61,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
   const int IHW = g.IH * g.IW;
 
   // ---- per-thread patch slots (position decode done once; channels advance by IHW / PS) ----
-  long long s_goff[CONV_MAXSLOT];
-  int s_loff[CONV_MAXSLOT];
+  // Loads go through buffer descriptors: an out-of-image / padded lane passes GMK_OOB and reads 0.
+  const long long n0 = p0 >> g.lgBHW;  // first image touched by this block (uniform)
+  long long nimg = g.N - n0;
+  if (nimg > g.nseg + 1) nimg = g.nseg + 1;
+  const __amdgpu_buffer_rsrc_t rx = gmk_make_rsrc(g.x + n0 * g.C * (long long)IHW, nimg * g.C * (long long)IHW * 4);
+  const __amdgpu_buffer_rsrc_t rw = gmk_make_rsrc(g.w, (long long)g.w_numel * 4);
+  int s_voff[NSLOT], s_loff[NSLOT];
 #pragma unroll
-  for (int k = 0; k < CONV_MAXSLOT; ++k) {
+  for (int k = 0; k < NSLOT; ++k) {
     int e = tid + k * 256;
-    s_goff[k] = -1;
+    s_voff[k] = GMK_OOB;
     s_loff[k] = -1;
     if (e < g.npos) {
       int seg = e / (PR * PC), r = e % (PR * PC);
@@ -71,8 +82,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
       int iy = r0 * SB + prow - ORG, ix = pcol - ORG;
       s_loff[k] = seg * CK * PS + prow * PC + pcol;
       if (n < g.N && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW)
-        s_goff[k] = (n * g.C) * (long long)IHW + iy * g.IW + ix;
+        s_voff[k] = (int)(((n - n0) * g.C * (long long)IHW + iy * g.IW + ix) * 4);
     }
+  }
+  // ---- per-thread weight slots: element e = tid + u*256 of the [MB][KC] chunk ----
+  int w_voff[NW], w_loff[NW];
+#pragma unroll
+  for (int u = 0; u < NW; ++u) {
+    const int e = tid + u * 256;
+    int m, c, t;
+    if (g.w_layout == 0) { m = e / KC; int r = e % KC; c = r / KK; t = r % KK; }
+    else { c = e / (MB * KK); int r = e % (MB * KK); m = r / KK; t = r % KK; }
+    const int gm = m0 + m;
+    const bool ok = (e < MB * KC) && gm < g.M;
+    w_voff[u] = ok ? (gm * g.w_m_stride + c * g.w_c_stride + t) * 4 : GMK_OOB;
+    const int tt = g.flip ? (KK - 1 - t) : t;
+    w_loff[u] = (e < MB * KC) ? m * WS + c * KK + tt : -1;
   }
 
   // ---- lane bases for the MFMA operand reads ----
@@ -90,32 +115,43 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][i][r] = 0.f;
 
-  for (int c0 = 0; c0 < g.C; c0 += CK) {
-    __syncthreads();
-    // stage the input patch chunk
+  float xr[NSLOT][CK], wr[NW];
+  // branch-free batched loads of one K-chunk into registers
+  auto load_chunk = [&](int c0) {
 #pragma unroll
-    for (int k = 0; k < CONV_MAXSLOT; ++k) {
-      if (s_loff[k] >= 0) {
+    for (int c = 0; c < CK; ++c) {
+      const bool cok = c0 + c < g.C;  // uniform
+      const int soff = cok ? (c0 + c) * IHW * 4 : 0;
 #pragma unroll
-        for (int c = 0; c < CK; ++c) {
-          float v = 0.f;
-          if (s_goff[k] >= 0 && c0 + c < g.C) v = g.x[s_goff[k] + (long long)(c0 + c) * IHW];
-          Xl[s_loff[k] + c * PS] = v;
-        }
+      for (int k = 0; k < NSLOT; ++k) xr[k][c] = gmk_buffer_load(rx, cok ? s_voff[k] : GMK_OOB, soff);
+    }
+    const int wsoff = c0 * g.w_c_stride * 4;
+    if (c0 + CK <= g.C) {
+#pragma unroll
+      for (int u = 0; u < NW; ++u) wr[u] = gmk_buffer_load(rw, w_voff[u], wsoff);
+    } else {  // ragged last chunk: mask the channels beyond C (channel index recovered from the LDS offset)
+#pragma unroll
+      for (int u = 0; u < NW; ++u) {
+        const int c = (w_loff[u] % WS) / KK;
+        wr[u] = gmk_buffer_load(rw, (c0 + c < g.C) ? w_voff[u] : GMK_OOB, wsoff);
       }
     }
-    // stage the weight chunk  Wl[m][c*KK + t]
-    for (int e = tid; e < MB * KC; e += 256) {
-      int m, c, t;
-      if (g.w_layout == 0) { m = e / KC; int r = e % KC; c = r / KK; t = r % KK; }
-      else { c = e / (MB * KK); int r = e % (MB * KK); m = r / KK; t = r % KK; }
-      const int gm = m0 + m, gc = c0 + c;
-      float v = 0.f;
-      if (gm < g.M && gc < g.C) v = g.w[(long long)gm * g.w_m_stride + (long long)gc * g.w_c_stride + t];
-      const int tt = g.flip ? (KK - 1 - t) : t;
-      Wl[m * WS + c * KK + tt] = v;
-    }
+  };
+
+  load_chunk(0);
+  for (int c0 = 0; c0 < g.C; c0 += CK) {
+    __syncthreads();  // previous chunk's LDS reads are done
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k)
+      if (s_loff[k] >= 0) {
+#pragma unroll
+        for (int c = 0; c < CK; ++c) Xl[s_loff[k] + c * PS] = xr[k][c];
+      }
+#pragma unroll
+    for (int u = 0; u < NW; ++u)
+      if (w_loff[u] >= 0) Wl[w_loff[u]] = wr[u];
     __syncthreads();
+    if (c0 + CK < g.C) load_chunk(c0 + CK);  // in flight during the MFMA loop below
     // MFMA over the chunk: k-step = (channel pair cp, tap t); lane half h takes channel 2cp+h
 #pragma unroll
     for (int cp = 0; cp < CK / 2; ++cp) {
@@ -216,14 +252,16 @@ static int gmk_launch_conv_impl(ConvGeom& g, int mode, hipStream_t s) {
   else { const int tlo = (KS - 1 - PAD) / 2, thi = (PAD + 1) / 2; g.PR = seg_rows + tlo + thi; g.PC = g.BW + tlo + thi; }
   g.PS = g.PR * g.PC;
   g.npos = g.nseg * g.PR * g.PC;
-  if (g.npos > 256 * CONV_MAXSLOT) return GMK_E_SHAPE;
+  if (g.npos > 256 * (mode == 1 ? 4 : 2)) return GMK_E_SHAPE;
   (void)BH;
   const size_t lds = sizeof(float) * ((size_t)MB * ((CK * KK) | 1) + (size_t)g.nseg * CK * g.PS);
   if (lds > 160 * 1024) return GMK_E_SHAPE;
   dim3 grid((unsigned)((g.total_base + PT - 1) / PT), (unsigned)((g.M + MB - 1) / MB));
+  const int nslot = (g.npos + 255) / 256;
 #define GMK_CONV_LAUNCH(MODE_, CK_, WM_, MT_)                                                              \
   do {                                                                                                     \
-    auto kern = conv_igemm_kernel<MODE_, KS, CK_, WM_, MT_>;                                               \
+    auto kern = (nslot <= GMK_NS_LO(MODE_)) ? conv_igemm_kernel<MODE_, KS, CK_, WM_, MT_, GMK_NS_LO(MODE_)> \
+                                            : conv_igemm_kernel<MODE_, KS, CK_, WM_, MT_, GMK_NS_HI(MODE_)>; \
     if (lds > 64 * 1024) {                                                                                 \
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return (int)e;                                                                  \

@@ -88,6 +88,17 @@ __device__ __forceinline__ void gmk_act_fwd(int act, float z, float& a, float& d
   }
 }
 
+// ---- buffer (SRD) loads: hardware bounds check returns 0 for out-of-range offsets, so padded /
+// masked tile loads need no branch and no select (an invalid lane passes GMK_OOB as its offset).
+#define GMK_OOB ((int)0x80000000)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gmk_make_rsrc(const void* base, long long bytes) {
+  const int nb = bytes > 0x7FFFFFF0ll ? 0x7FFFFFF0 : (int)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, nb, 0x00020000);
+}
+__device__ __forceinline__ float gmk_buffer_load(__amdgpu_buffer_rsrc_t r, int voffset_bytes, int soffset_bytes) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voffset_bytes, soffset_bytes, 0));
+}
+
 // wave64 sum reduction (all lanes get the result in lane 0; use after per-thread partials)
 __device__ __forceinline__ double gmk_wave_sum(double v) {
 #pragma unroll
