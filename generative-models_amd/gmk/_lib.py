@@ -39,6 +39,11 @@ SIGNATURES = {
     "gmk_upsample2_bwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
     "gmk_ew_mul": (_I, [_P, _P, _P, _L, _P]),
     "gmk_adamw_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P]),
+    "gmk_gram_workspace_bytes": (_Z, [_L, _I]),
+    "gmk_gram_accumulate": (_I, [_P, _L, _I, _P, _P, _P, _Z, _P]),
+    "gmk_fid_workspace_bytes": (_Z, [_I]),
+    "gmk_fid_from_moments": (_I, [_P, _P, _L, _P, _P, _L, _I, _I, C.c_double, C.c_double, _P, _P, _Z, _P]),
+    "gmk_softmax_stats": (_I, [_P, _L, _I, _I, _F, _P, _P]),
     "gmk_vae_loss_workspace_bytes": (_Z, []),
     "gmk_vae_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _F, _I, _P, _Z, _P]),
 }

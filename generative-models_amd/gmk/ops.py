@@ -222,3 +222,34 @@ def ew_mul(a, b):
     out = torch.empty_like(a)
     check(lib().gmk_ew_mul(_p(a), _p(b), _p(out), a.numel(), _stream()))
     return out
+
+
+def gram_accumulate(x, G, s):
+    """G (D,D) f64 += x^T x ; s (D) f64 += x.sum(0) for fp32 features x (n, D)."""
+    _chk(x)
+    n, D = x.shape
+    ws = workspace(lib().gmk_gram_workspace_bytes(n, D), x.device)
+    check(lib().gmk_gram_accumulate(_p(x), n, D, G.data_ptr(), s.data_ptr(), _p(ws), ws.numel(), _stream()))
+
+
+def fid_from_moments(m1, m2, iters=50, delta=1e-12, diag_eps=0.0):
+    """m = (n, s f64 (D), G f64 (D,D)).  Returns an 8-double device tensor
+    {dmu2, tr1, tr2, fro, c, tr_sqrt, fid, -}."""
+    n1, s1, G1 = m1
+    n2, s2, G2 = m2
+    D = s1.numel()
+    out = torch.zeros(8, dtype=torch.float64, device=s1.device)
+    ws = workspace(lib().gmk_fid_workspace_bytes(D), s1.device)
+    check(lib().gmk_fid_from_moments(G1.data_ptr(), s1.data_ptr(), int(n1), G2.data_ptr(), s2.data_ptr(), int(n2), D,
+                                     int(iters), float(delta), float(diag_eps), out.data_ptr(), _p(ws), ws.numel(), _stream()))
+    return out
+
+
+def softmax_stats(logits, out=None, topn=3, eps=1e-7):
+    """Accumulates the (2C+4)-double statistics vector of gmk_softmax_stats for logits (n, C)."""
+    _chk(logits)
+    n, C = logits.shape
+    if out is None:
+        out = torch.zeros(2 * C + 4, dtype=torch.float64, device=logits.device)
+    check(lib().gmk_softmax_stats(_p(logits), n, C, int(topn), float(eps), out.data_ptr(), _stream()))
+    return out

@@ -221,6 +221,22 @@ class Autoencoder(nn.Module):
         from utils import save_image_grid
         save_image_grid(out.detach().cpu(), f'plots/samples_{name}.png', nrow=4, figsize=(7, 4.5))
 
+    @torch.no_grad()
+    def encode_features(self, x):
+        """latent_vector of `x` without running the decoder (what metrics.compute_fid consumes;
+        the reference runs the full model and discards the reconstruction, metrics.py:70-73)."""
+        enc = self.encoder
+        pe = {n: p.data for n, p in enc.named_parameters()}
+        out, _ = engine.encoder_forward(pe, x.contiguous(), act=enc._act_id, no_pool=enc.no_pool,
+                                        ksize=enc.kernel_size, train=False)
+        if self.variational:
+            self.stats = out.view(x.shape[0], self.latent_size, 2)
+            self.normal = torch.randn((x.shape[0], self.latent_size), device=x.device, dtype=torch.float32)
+            self.latent_vector = ops.reparam_fwd(self.stats, self.normal)
+        else:
+            self.latent_vector = out
+        return self.latent_vector
+
     # ------------------------------------------------------------------ fused train step
     def train_step(self, image, beta=0.0, mse_prior=False, eps=None, reducer=None):
         """Forward + fused loss + backward of /root/reference/main.py:29-51 without autograd.

@@ -158,6 +158,32 @@ int gmk_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, floa
                    float beta2, float eps, float weight_decay, int64_t step, float gscale,
                    gmk_stream_t stream);
 
+/* ---------------------------------------------------------------- FID / inception stats --
+ * gmk_gram_accumulate: n fp32 feature rows X (n, D) -> G (D,D) += X^T X, s (D) += column sums, both
+ *   fp64, on v_mfma_f64_16x16x4_f64 (products of fp32 values are exact in fp64, so the moments do
+ *   not depend on how samples are sharded over calls or GPUs beyond ~1e-16 relative).
+ *   replaces np.cov / mean of /root/reference/metrics.py:75-79 (moments are combined across ranks
+ *   with ONE all-reduce of (n, s, G) by the host side).  G, s must be zeroed by the caller first. */
+size_t gmk_gram_workspace_bytes(int64_t n, int D);
+int gmk_gram_accumulate(const float* X, int64_t n, int D, double* G, double* s, void* ws, size_t ws_bytes,
+                        gmk_stream_t stream);
+/* gmk_fid_from_moments: mu = s/n, Sigma = (G - s s^T/n)/(n-1) + diag_eps*I for both sets, then
+ *   fid = |mu1-mu2|^2 + tr S1 + tr S2 - 2 tr sqrt(S1 S2), with tr sqrt(S1 S2) = tr sqrt(S1^1/2 S2 S1^1/2)
+ *   from two symmetric coupled Newton-Schulz square roots (`iters` iterations each, relative ridge
+ *   `delta`), fp64 MFMA GEMMs, no host synchronisation.
+ *   replaces scipy.linalg.sqrtm + the trace formula of metrics.py:90-108.
+ *   out: 8 doubles on device {dmu2, tr1, tr2, fro, c, tr_sqrt, fid, -}. */
+size_t gmk_fid_workspace_bytes(int D);
+int gmk_fid_from_moments(const double* G1, const double* s1, int64_t n1, const double* G2, const double* s2,
+                         int64_t n2, int D, int iters, double delta, double diag_eps, double* out,
+                         void* ws, size_t ws_bytes, gmk_stream_t stream);
+/* gmk_softmax_stats: logits (n, C<=32) -> out (2C+4 doubles, ACCUMULATED; zero first):
+ *   [0,C) sum p ; [C,2C) arg-max histogram ; [2C] sum_n -sum_c p log(p+eps) ; [2C+1] sum top-1 ;
+ *   [2C+2] sum top-N ; [2C+3] n.   replaces metrics.py:144-169 and :231-253 (one all-reduce of `out`
+ *   combines ranks). */
+int gmk_softmax_stats(const float* logits, int64_t n, int C, int topn, float eps, double* out,
+                      gmk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
