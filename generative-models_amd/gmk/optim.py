@@ -23,8 +23,8 @@ class FusedAdamW(torch.optim.AdamW):
     def _flatten(self):
         ps = self.param_groups[0]["params"]
         dev = ps[0].device
-        if dev.type != "cuda" or any(p.device != dev or p.dtype != torch.float32 for p in ps):
-            raise RuntimeError("FusedAdamW needs fp32 parameters on one CUDA device (move the model first)")
+        if any(p.device != dev or p.dtype != torch.float32 for p in ps):
+            raise RuntimeError("FusedAdamW needs fp32 parameters on one device (move the model first)")
         sizes = [p.numel() for p in ps]
         # every tensor starts on a 4-float (16-byte) boundary so kernels can use float4 everywhere
         self._offsets, off = [], 0
@@ -87,6 +87,8 @@ class FusedAdamW(torch.optim.AdamW):
             self._flatten()  # someone re-assigned p.data / p.grad (e.g. model.to()): re-home them
         group = self.param_groups[0]
         ps = group["params"]
+        if self.flat_param.device.type != "cuda":
+            raise RuntimeError("FusedAdamW.step() runs a gfx950 kernel: parameters must be on an MI355X (no CPU path)")
         # state['step'] bookkeeping exactly like torch (a float32 scalar tensor per parameter)
         for p, o in zip(ps, self._offsets):
             st = self.state[p]

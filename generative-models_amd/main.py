@@ -1,0 +1,236 @@
+"""Training driver with the reference's CLI, experiment string and checkpoint layout
+(/root/reference/main.py).  The hot loop (main.py:27-53 there) runs on libgmk kernels through
+`model.train_step` (forward + fused sigmoid/MSE/KL loss kernel + backward, no autograd), a fused
+AdamW launch and, under torchrun, a bucketed RCCL gradient all-reduce overlapped with backward.
+
+    python main.py --latent_size 256 --sigmoid --wd 0.01 --epochs 100 --train --no_upsample --no_pool
+    python main.py --latent_size 256 --sigmoid --wd 0.01 --epochs 100 --train --no_upsample --no_pool --variational
+    torchrun --nproc_per_node 8 main.py ... (data parallel; every rank sees its own shuffled batches)
+
+Kept quirks of the reference: checkpoint['epoch'] stores the completed epoch and resume starts at
+it (main.py:221,264,328); beta grows per epoch (main.py:65-66); losses are printed x1000.
+"""
+import os
+from datetime import datetime
+
+import torch
+
+from arguments import get_args_parser
+from dataloaders import get_cifar
+from metrics import compute_fid, compute_confidence_diversity, compute_inception_score
+from models.autoencoders import Autoencoder
+from utils import get_activation_function, plot_grid, make_folder
+from gmk.optim import FusedAdamW
+from gmk.parallel import GradReducer, init_from_env
+
+
+def train_one_epoch(args, model, epoch=None, beta=None, train_dataloader=None, optim=None, lr_scheduler=None,
+                    device=None, writer=None, reducer=None):
+    model.train()
+    total = torch.zeros(3, device=device)
+    count = 0
+    for image, label in train_dataloader:
+        image = image.to(device)
+        # forward + loss + backward (main.py:29-51): grads land in the optimizer's flat buffer
+        losses = model.train_step(image, beta=beta if args.variational else 0.0, mse_prior=args.mse, reducer=reducer)
+        if reducer is not None:
+            reducer.wait()
+        optim.step()
+        lr_scheduler.step()
+        total += losses
+        if writer is not None:
+            i = epoch * len(train_dataloader) + count
+            rec, kl, tot = losses.tolist()
+            if args.variational:
+                writer.add_scalar('Train Loss/KL', kl, i)
+            writer.add_scalar('Train Loss/Reconstruction', rec, i)
+            writer.add_scalar('Train Loss/Total', tot, i)
+            writer.add_scalar('Train Loss/beta', beta, i)
+        count += 1
+    avg_train_rec_loss = total[0] / len(train_dataloader)
+    avg_train_kl_loss = beta * total[1] / len(train_dataloader) if args.variational else 0
+    if args.variational:  # to combat vanishing KL loss
+        beta *= args.beta_mult
+    return beta, avg_train_rec_loss, avg_train_kl_loss
+
+
+def compute_test_loss(args, model, beta=None, test_dataloader=None, device=None):
+    """main.py:73-111: eval-mode losses plus mean |mu| and mean sigma of the latent."""
+    import torch.nn.functional as F
+    model.eval()
+    with torch.no_grad():
+        total_test_rec_loss = 0
+        total_test_kl_loss = 0
+        latent_mean = 0
+        latent_std = 0
+        for test_image, label in test_dataloader:
+            test_image = test_image.to(device)
+            test_reconstructed = model(test_image)
+            total_test_rec_loss += F.mse_loss(test_reconstructed, test_image)
+            if args.variational:
+                mu = model.stats[:, :, 0]
+                log_var = model.stats[:, :, 1]
+                sigma = torch.exp(0.5 * log_var)
+                if args.mse:
+                    test_kl_loss = (mu ** 2).sum(1).mean(0) + ((sigma - 1) ** 2).sum(1).mean(0)
+                else:
+                    test_kl_loss = torch.mean(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=0)
+                total_test_kl_loss += test_kl_loss
+                latent_mean += mu.abs().mean()
+                latent_std += sigma.abs().mean()
+        num_test_batches = len(test_dataloader)
+        avg_test_kl_loss = beta * total_test_kl_loss / num_test_batches
+        avg_test_rec_loss = total_test_rec_loss / num_test_batches
+        return latent_mean / num_test_batches, latent_std / num_test_batches, avg_test_rec_loss, avg_test_kl_loss
+
+
+def compute_metrics(autoencoder=None, classifier=None, real_images=None, samples=None, debug=False):
+    fid_ae = compute_fid(model=autoencoder, images1=real_images, images2=samples)
+    fid_classifier = compute_fid(model=classifier, images1=real_images, images2=samples)
+    confidence, diversity = compute_confidence_diversity(classifier, samples, debug=debug)
+    inception_score = compute_inception_score(classifier=classifier, images=samples)
+    return fid_classifier, fid_ae, confidence, diversity, inception_score
+
+
+def main(args):
+    for dir_name in ['checkpoints', 'data', 'plots', 'logs']:
+        make_folder(dir_name)
+    rank, local, world = init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit('this build runs on MI355X GPUs only (libgmk has no CPU path)')
+    device = torch.device('cuda', local)
+
+    train_dataloader, test_dataloader = get_cifar(data_dir=args.data_dir, train_batch_size=args.train_batch_size,
+                                                  test_batch_size=args.test_batch_size)
+    if os.path.isfile('data/train_examples.pth') and os.path.isfile('data/test_examples.pth'):
+        train_input_images = torch.load('data/train_examples.pth')
+        test_input_images = torch.load('data/test_examples.pth')
+    else:
+        train_input_images = next(iter(train_dataloader))[0]
+        test_input_images = next(iter(test_dataloader))[0]
+        torch.save(train_input_images, 'data/train_examples.pth')
+        torch.save(test_input_images, 'data/test_examples.pth')
+    if test_input_images.shape[0] < args.latent_size:
+        print(f'\n\nNumber of test images {test_input_images.shape[0]} should be >= number of '
+              f'features {args.latent_size} in order to compute FID properly (only applies to VAE)\n\n')
+        if args.variational:
+            raise(SystemExit)
+
+    args.act_fn = get_activation_function(act_str=args.act)
+    if args.checkpoint is not None:
+        print(f'\n\nLoading model checkpoint from {args.checkpoint}')
+        # reference checkpoints pickle `args` (with an nn.Module inside): not weights_only-loadable
+        checkpoint = torch.load(args.checkpoint, weights_only=False)
+
+    model = Autoencoder(variational=args.variational, latent_size=args.latent_size, num_channels=args.num_channels,
+                        kernel_size=args.kernel_size, act=args.act_fn, sigmoid=args.sigmoid,
+                        interpolation=args.interpolation, no_pool=args.no_pool, no_upsample=args.no_upsample,
+                        device=device, debug=args.debug).to(device)
+    beta = args.beta
+    init_epoch = 0
+    if args.variational:
+        model_type = f'vae_{args.beta}x{args.beta_mult}'
+        if os.path.isfile(args.ae_checkpoint):
+            print(f'\n\nLoading pretrained VAE for FID computation from {args.ae_checkpoint}')
+            plain_ae = torch.load(args.ae_checkpoint, weights_only=False)
+        else:
+            print(f'\n\nTo compute FID score using a plain autoencoder, provide valid path to checkpoint, or train one:')
+            print(f'\n\npython main.py --latent_size 256 --sigmoid --wd 0.01 --epochs 100 --train --no_upsample --no_pool\n\n')
+            raise(SystemExit)
+        from models.classifiers import evaluate_classifier, train_classifier
+        classifier_checkpoint = args.classifier_checkpoint or f'checkpoints/cifar_classifier_{args.latent_size}.pth'
+        if os.path.isfile(classifier_checkpoint):
+            classifier = torch.load(classifier_checkpoint, weights_only=False)
+            test_acc = evaluate_classifier(classifier, test_dataloader=test_dataloader, device=device)
+            print(f'\n\nCIFAR-10 Test Accuracy {test_acc:.2f}')
+        else:
+            print(f'\n\nClassifier checkpoint is not found at {classifier_checkpoint}')
+            classifier = train_classifier(args, classifier=None, train_dataloader=train_dataloader,
+                                          test_dataloader=test_dataloader, device=device)
+        if isinstance(plain_ae, dict) or isinstance(classifier, dict):
+            raise NotImplementedError('\n\nmodel checkpoint must be a full saved model, not a state_dict\n\n')
+    else:
+        model_type = 'plain-ae'
+
+    if args.checkpoint is not None:
+        model.load_state_dict(checkpoint['state_dict'])
+    if world > 1:
+        for p in model.parameters():
+            torch.distributed.broadcast(p.data, src=0)
+    optim = FusedAdamW(model.parameters(), lr=args.lr, weight_decay=args.wd)
+    lr_scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optim, T_max=args.epochs * len(train_dataloader))
+    reducer = GradReducer(model, optim) if world > 1 else None
+    if args.checkpoint is not None:
+        optim.load_state_dict(checkpoint['optimizer'])
+        lr_scheduler.load_state_dict(checkpoint['lr_scheduler'])
+        init_epoch = checkpoint['epoch']
+        beta = checkpoint['current_beta']
+
+    pool_str = 'pool-stride' if args.no_pool else 'pool-max'
+    upsample_str = 'upsample-deconv' if args.no_upsample else f'upsample-{args.interpolation}'
+    experiment_str = args.tag + f'{model_type}_latent{args.latent_size}_chan{args.num_channels}_{pool_str}_{upsample_str}_bs{args.train_batch_size}_lr{args.lr}_wd{args.wd}_e{args.epochs}'
+    print(f'\n\n{experiment_str}')
+
+    writer = None
+    if args.log_tb:
+        try:
+            from torch.utils.tensorboard import SummaryWriter
+            writer = SummaryWriter(args.tb_dir + '/' + experiment_str)
+        except ImportError:
+            print('tensorboard is not installed: --log_tb ignored')
+
+    if args.evaluate:
+        plot_grid(model, train_input_images[:4], name=experiment_str + '_train')
+        plot_grid(model, test_input_images[:4], name=experiment_str + '_test')
+    if args.sample:
+        model.sample(name=experiment_str)
+
+    if args.train:
+        ref_metrics_str = ''
+        if args.variational:
+            fid_classifier, fid_ae, confidence, diversity, inception_score = compute_metrics(
+                autoencoder=plain_ae, classifier=classifier, real_images=train_input_images.to(device),
+                samples=test_input_images.to(device), debug=True)
+            ref_metrics_str = f'Reference (real images) metrics:  FID (classifier/AE): ' + \
+                f'{fid_classifier:.1f}/{fid_ae:.1f}  confidence {confidence:.1f}  diversity {diversity:.1f}  IS {inception_score:.3f}\n\n'
+        print(f'\n\nTraining {model_type} model on CIFAR-10 images\n\n{ref_metrics_str}')
+
+        for epoch in range(init_epoch, args.epochs, 1):
+            beta, avg_train_rec_loss, avg_train_kl_loss = train_one_epoch(
+                args, model, epoch=epoch, beta=beta, train_dataloader=train_dataloader, optim=optim,
+                lr_scheduler=lr_scheduler, device=device, writer=writer, reducer=reducer)
+            avg_latent_mean, avg_latent_std, avg_test_rec_loss, avg_test_kl_loss = compute_test_loss(
+                args, model, beta=beta, test_dataloader=test_dataloader, device=device)
+            metrics_str = ''
+            if args.variational:
+                samples = model.sample(num_images=args.test_batch_size, return_samples=True)
+                fid_classifier, fid_ae, confidence, diversity, inception_score = compute_metrics(
+                    autoencoder=plain_ae, classifier=classifier, real_images=test_input_images.to(device),
+                    samples=samples, debug=True)
+                metrics_str = f'  FID (classifier/AE): {fid_classifier:.1f}/{fid_ae:.1f}  confidence {confidence:.1f}  diversity {diversity:.1f}  IS {inception_score:.2f}'
+            latent_stats_str = f'  mean {avg_latent_mean:.4f} std {avg_latent_std:.4f}' if args.variational else ''
+            kl_loss_str = f'  kl train {1000*avg_train_kl_loss:.2f} test {1000*avg_test_kl_loss:.2f}' if args.variational else ''
+            loss_str = f'losses:  train {1000*avg_train_rec_loss:.2f} test {1000*avg_test_rec_loss:.2f}{kl_loss_str}'
+            changes_str = f'  LR {lr_scheduler.get_last_lr()[0]:.5f}' + (f' beta {beta:.6f}' if args.variational else '')
+            time_str = f'{str(datetime.now())[:-7]}'
+            if rank == 0:
+                print(f'{time_str}  Epoch {epoch:>3d}   {loss_str}{latent_stats_str}{metrics_str}{changes_str}')
+                plot_grid(model, train_input_images[:4], name=experiment_str + '_train')
+                plot_grid(model, test_input_images[:4], name=experiment_str + '_test')
+                checkpoint = {}
+                checkpoint['state_dict'] = model.state_dict()
+                checkpoint['optimizer'] = optim.state_dict()
+                checkpoint['lr_scheduler'] = lr_scheduler.state_dict()
+                checkpoint['epoch'] = epoch
+                checkpoint['args'] = args
+                checkpoint['current_beta'] = beta
+                checkpoint['losses'] = loss_str
+                torch.save(checkpoint, 'checkpoints/' + experiment_str + ".pth")
+                model.sample(name=experiment_str)
+        if rank == 0 and not os.path.isfile(args.ae_checkpoint):  # save full model checkpoint
+            torch.save(model, 'checkpoints/' + experiment_str + "_full_model.pth")
+
+
+if __name__ == "__main__":
+    args = get_args_parser().parse_args()
+    main(args)
