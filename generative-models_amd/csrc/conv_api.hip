@@ -3,6 +3,7 @@
 //   conv fwd s1 -> MODE0, s2 -> MODE1 ; conv dgrad s1 -> MODE0 with flipped taps and [c][m] weights,
 //   s2 -> MODE2 ; deconv fwd -> MODE2 ; deconv dgrad -> MODE1.
 #include "conv_igemm.h"
+#include <stdlib.h>
 
 static int conv_common_checks(int N, int Cin, int H, int W, int Cout, int ksize) {
   if (N <= 0 || Cin <= 0 || Cout <= 0) return GMK_E_SHAPE;
@@ -12,6 +13,8 @@ static int conv_common_checks(int N, int Cin, int H, int W, int Cout, int ksize)
 }
 
 static int dispatch(ConvGeom& g, int ksize, int mode, hipStream_t s) {
+  static const int dbg = getenv("GMK_CONV_DBG") ? atoi(getenv("GMK_CONV_DBG")) : 0;  // profiling ablations only
+  g.dbg = dbg;
   return ksize == 3 ? gmk_launch_conv_k3(g, mode, s) : gmk_launch_conv_k5(g, mode, s);
 }
 

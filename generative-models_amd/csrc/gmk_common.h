@@ -56,10 +56,19 @@ __device__ __forceinline__ void gmk_act_fwd(int act, float z, float& a, float& d
       break;
     }
     case GMK_ACT_GELU: {
-      float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752440f));
-      float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
+      // exact-erf GELU and its derivative from ONE exponential: e = exp(-z^2/2) serves both the pdf and
+      // erf(z/sqrt2) = sign(z) (1 - P(t) e), t = 1/(1 + p |z|/sqrt2)  (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7)
+      const float ax = fabsf(z) * 0.70710678118654752440f;
+      const float e = __expf(-ax * ax);
+      const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+      float p = fmaf(1.061405429f, t, -1.453152027f);
+      p = fmaf(p, t, 1.421413741f);
+      p = fmaf(p, t, -0.284496736f);
+      p = fmaf(p, t, 0.254829592f);
+      const float q = 0.5f * p * t * e;          // 0.5 * erfc(|z|/sqrt2)
+      const float cdf = z >= 0.f ? 1.0f - q : q;
       a = z * cdf;
-      d = cdf + z * pdf;
+      d = fmaf(z * 0.39894228040143267794f, e, cdf);
       break;
     }
     case GMK_ACT_SILU: {
