@@ -1,5 +1,6 @@
 // conv_wgrad_api.hip -- C-ABI entry points for conv / deconv weight + bias gradients.
 #include "conv_wgrad.h"
+#include "conv_wgrad_thin.h"
 
 static void wgrad_plan(WgradGeom& g, int N, int Cs, int Cb, int SH, int SW, int ksize, int sb) {
   g.N = N; g.Cs = Cs; g.Cb = Cb; g.SH = SH; g.SW = SW; g.BHt = SH * sb; g.BWt = SW * sb;
@@ -25,7 +26,16 @@ static size_t wgrad_ws_bytes(int N, int Cs, int Cb, int SH, int SW, int ksize, i
   return slab_bytes(g, ksize) + 256;
 }
 
+// stride-1 convs with a thin input or output (<= 8 channels, e.g. the 3 image channels) take the dedicated kernel
+static bool thin_route(ThinGeom& t, int N, int Cin, int H, int W, int Cout, int ksize, int stride, bool want_bias) {
+  if (stride != 1 || (ksize != 3 && ksize != 5)) return false;
+  if (Cin < Cout) return gmk_thin_plan(t, N, Cout, Cin, H, W, ksize, +1, want_bias);
+  return gmk_thin_plan(t, N, Cin, Cout, H, W, ksize, -1, want_bias);
+}
+
 extern "C" size_t gmk_conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int ksize, int stride) {
+  ThinGeom t{};
+  if (thin_route(t, N, Cin, H, W, Cout, ksize, stride, true)) return gmk_thin_slab_bytes(t) + 256;
   return wgrad_ws_bytes(N, Cout, Cin, H / stride, W / stride, ksize, stride, Cout);
 }
 extern "C" size_t gmk_deconv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int ksize) {
@@ -50,6 +60,13 @@ extern "C" int gmk_conv2d_wgrad(const float* dy, const float* x, float* dw, floa
                                 gmk_stream_t stream) {
   GMK_REQUIRE(dy && x && dw && ws, GMK_E_NULL);
   GMK_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2), GMK_E_SHAPE);
+  ThinGeom t{};
+  if (thin_route(t, N, Cin, H, W, Cout, ksize, stride, dbias != nullptr)) {
+    if (!gmk_aligned16(ws) || !gmk_aligned16(dy) || !gmk_aligned16(x)) return GMK_E_ALIGN;
+    if (ws_bytes < gmk_thin_slab_bytes(t)) return GMK_E_WORKSPACE;
+    t.wide = t.sgn > 0 ? dy : x; t.thin = t.sgn > 0 ? x : dy; t.slab = (float*)ws;
+    return gmk_launch_wgrad_thin(t, ksize, dw, dbias, (hipStream_t)stream);
+  }
   return wgrad_run(dy, x, dw, dbias, 1, N, Cout, Cin, H / stride, W / stride, ksize, stride, ws, ws_bytes,
                    (hipStream_t)stream);
 }

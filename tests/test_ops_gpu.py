@@ -49,6 +49,16 @@ CONV_SHAPES = [
     (1, 16, 64, 64, 16, 3, 1),
     (16, 64, 16, 16, 64, 3, 1),   # enough base positions for the 64x128 tile
     (3, 24, 8, 8, 40, 3, 1),      # ragged channel counts
+    # thin-channel wgrad kernel (conv_wgrad_thin.h): thin input / thin output, ragged + multi-tile wide side, k=5,
+    # 64x64 images, and enough 256-pixel chunks (N*H*W/256 > 256 blocks) for several double-buffered iterations
+    (3, 3, 64, 64, 16, 3, 1),
+    (2, 16, 32, 32, 3, 3, 1),
+    (2, 3, 32, 32, 80, 3, 1),
+    (2, 3, 32, 32, 8, 5, 1),
+    (2, 40, 16, 16, 2, 5, 1),
+    (1, 1, 16, 16, 4, 3, 1),
+    (200, 3, 32, 32, 64, 3, 1),
+    (200, 32, 32, 32, 3, 3, 1),
 ]
 
 
