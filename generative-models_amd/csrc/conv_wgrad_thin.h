@@ -9,8 +9,8 @@
 //
 // GEMM view: M = 64 wide channels (A operand), N = Ct*k*k (+1) columns padded to 32*NB (B operand, read
 // from the zero-padded thin patch in LDS at a per-lane tap offset), K = pixels.  The kernel is HBM-bound
-// (one pass over the wide tensor): 512-thread blocks stream 256-pixel chunks through a double-buffered
-// LDS tile, each of the 8 waves reduces 32 pixels of the chunk, partials are combined in LDS in a fixed
+// (one pass over the wide tensor): 512-thread blocks each take 4 consecutive 256-pixel chunks, prefetch all of them into
+// registers and pass them through one LDS tile, each of the 8 waves reduces 32 pixels of the chunk, partials are combined in LDS in a fixed
 // order and one slab per block is written; a second kernel sums the slabs (deterministic, no atomics).
 #pragma once
 #include "gmk_common.h"
@@ -28,17 +28,22 @@ struct ThinGeom {
 };
 
 #define GMK_THIN_PX 256
+#define GMK_THIN_SS 260  /* LDS row stride of the wide tile (floats): 16-byte rows */
 #define GMK_THIN_THREADS 512
 #define GMK_THIN_TSLOT 3
+#define GMK_THIN_CPB 4  /* chunks per block */
 
 template <int KS, int NB>
 __global__ __launch_bounds__(GMK_THIN_THREADS) void conv_wgrad_thin_kernel(const ThinGeom g) {
   constexpr int KK = KS * KS, PAD = (KS - 1) / 2, NCB = 32 * NB;
-  constexpr int PX = GMK_THIN_PX, SS = PX + 1, NT = GMK_THIN_THREADS;
+  constexpr int PX = GMK_THIN_PX, SS = GMK_THIN_SS, NT = GMK_THIN_THREADS;
   constexpr int NS = (64 * PX / 4) / NT;  // float4 loads of the wide tile per thread and chunk
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // Wide tile [64][SS] with 16-byte rows (ds_write_b128) and the column index XOR-swizzled by (row>>3)&3 so
+  // that the 32 rows an MFMA A read touches fall into 32 different banks; thin patch behind it.
+  float* Wl = smem;
+  float* Tl = smem + 64 * SS;
   const int PS = g.PS, PC = g.PC;
-  const int tile_floats = 64 * SS + ((g.npos + 3) & ~3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, jj = lane & 31;
   const int wt = blockIdx.y, wc0 = wt * 64;
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(GMK_THIN_THREADS) void conv_wgrad_thin_kernel(const
 #pragma unroll
   for (int k = 0; k < GMK_THIN_TSLOT; ++k) {
     const int e = tid + k * NT;
-    t_loff[k] = e < g.npos ? e : -1;
+    t_loff[k] = e < g.npos ? e : g.npos;  // masked slots land in the trash word behind the patch
     const int tc = e / PS, r = e % PS;
     t_prow[k] = r / PC - PAD;
     t_pcol[k] = r % PC - PAD;
@@ -79,9 +84,20 @@ __global__ __launch_bounds__(GMK_THIN_THREADS) void conv_wgrad_thin_kernel(const
       for (int r = 0; r < 16; ++r) acc[i][nb][r] = 0.f;
   float bsum = 0.f;
 
-  float4 wr[NS];
-  float tr[GMK_THIN_TSLOT];
-  auto load_chunk = [&](long long ch) {
+  // A block owns GMK_THIN_CPB consecutive chunks and issues ALL of their loads up front into registers
+  // (the whole kernel is only ~4 HBM latencies long); the MFMAs then run as the data lands.  Straight-line
+  // code on purpose: inside a loop the compiler cannot count the outstanding loads and falls back to
+  // s_waitcnt vmcnt(0), draining the whole prefetch queue at every chunk.
+  constexpr int DEPTH = GMK_THIN_CPB;
+  struct Stage { float4 w[NS]; float t[GMK_THIN_TSLOT]; };
+  Stage R[DEPTH];
+  // Loads and LDS stores are unconditional and branch-free (a chunk index past the end re-reads the last
+  // chunk, a masked patch slot reads offset GMK_OOB -> 0 and lands in a trash word): with any of them under
+  // a branch the compiler can no longer count outstanding loads and falls back to s_waitcnt vmcnt(0),
+  // which drains the whole prefetch queue at every chunk.
+  const long long last_chunk = g.total_chunks - 1;
+  auto load_chunk = [&](Stage& st, long long ch) {
+    ch = ch < last_chunk ? ch : last_chunk;
     const long long pix = ch * PX;
     const long long n = pix >> g.lgHW;
     const int pin = (int)(pix & (HW - 1));
@@ -89,52 +105,48 @@ __global__ __launch_bounds__(GMK_THIN_THREADS) void conv_wgrad_thin_kernel(const
     const float* wbase = g.wide + ((n * g.Cw + wc0) << g.lgHW) + pin;
     const __amdgpu_buffer_rsrc_t rt = gmk_make_rsrc(g.thin + ((n * g.Ct) << g.lgHW), (long long)g.Ct * HW * 4);
 #pragma unroll
-    for (int u = 0; u < NS; ++u) {
-      const int e = tid + u * NT;
-      const int c = e / (PX / 4), p4 = e % (PX / 4);
-      const int cc = c < cw ? c : cw - 1;  // ragged wide tile: re-read the last valid channel, zeroed in store_chunk
-      wr[u] = *(const float4*)(wbase + ((size_t)cc << g.lgHW) + p4 * 4);
-    }
-#pragma unroll
     for (int k = 0; k < GMK_THIN_TSLOT; ++k) {
       const int iy = r0 + t_prow[k], ix = t_pcol[k];
-      const bool ok = t_loff[k] >= 0 && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
-      tr[k] = gmk_buffer_load(rt, ok ? (t_goff[k] + iy * g.W + ix) * 4 : GMK_OOB, 0);
+      const bool ok = (t_loff[k] < g.npos) & (iy >= 0) & (iy < g.H) & (ix >= 0) & (ix < g.W);
+      st.t[k] = gmk_buffer_load(rt, ok ? (t_goff[k] + iy * g.W + ix) * 4 : GMK_OOB, 0);
     }
-  };
-  auto store_chunk = [&](float* buf) {
-    float* Tl = buf + 64 * SS;
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
-      const int e = tid + u * NT;
-      const int c = e / (PX / 4), p4 = e % (PX / 4);
-      float* d = buf + c * SS + p4 * 4;
-      const bool okc = c < cw;
-      d[0] = okc ? wr[u].x : 0.f;
-      d[1] = okc ? wr[u].y : 0.f;
-      d[2] = okc ? wr[u].z : 0.f;
-      d[3] = okc ? wr[u].w : 0.f;
+      const int c = wave + u * (NT / 64);  // one 1-KiB channel row per wave instruction
+      const int cc = c < cw ? c : cw - 1;  // ragged wide tile: re-read the last valid channel, zeroed in store_chunk
+      st.w[u] = *(const float4*)(wbase + ((size_t)cc << g.lgHW) + lane * 4);
     }
+  };
+  auto store_chunk = [&](const Stage& st) {
 #pragma unroll
-    for (int k = 0; k < GMK_THIN_TSLOT; ++k)
-      if (t_loff[k] >= 0) Tl[t_loff[k]] = tr[k];
+    for (int k = 0; k < GMK_THIN_TSLOT; ++k) Tl[t_loff[k]] = st.t[k];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int c = wave + u * (NT / 64);
+      const int sw = (c >> 3) & 3;  // wave-uniform swizzle: element k of the quad goes to slot k ^ sw
+      float4 v = st.w[u];
+      if (c >= cw) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (sw & 1) v = make_float4(v.y, v.x, v.w, v.z);
+      if (sw & 2) v = make_float4(v.z, v.w, v.x, v.y);
+      *(float4*)(Wl + c * SS + lane * 4) = v;
+    }
   };
 
-  long long ch = blockIdx.x;
-  int it = 0;
-  if (ch < g.total_chunks) {
-    load_chunk(ch);
-    store_chunk(smem);
-    if (ch + g.G < g.total_chunks) load_chunk(ch + g.G);
-  }
-  __syncthreads();
-  for (; ch < g.total_chunks; ch += g.G, ++it) {
-    const float* Wl = smem + (it & 1) * tile_floats;
-    const float* Tl = Wl + 64 * SS;
+  const int asw = (jj >> 3) & 3;  // rows jj and 32+jj share the swizzle
+  const long long ch0 = (long long)blockIdx.x * DEPTH;
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load_chunk(R[d], ch0 + d);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    gmk_lds_barrier();  // previous chunk's LDS reads are done (global loads stay in flight)
+    store_chunk(R[d]);
+    gmk_lds_barrier();
+    if (ch0 + d > last_chunk) continue;  // uniform: the clamped re-read of the last chunk is not accumulated
 #pragma unroll 4
     for (int s = 0; s < PX / 16; ++s) {
       const int p = wave * (PX / 8) + 2 * s + h;
-      const float a0 = Wl[jj * SS + p], a1 = Wl[(32 + jj) * SS + p];
+      const int pa = p ^ asw;
+      const float a0 = Wl[jj * SS + pa], a1 = Wl[(32 + jj) * SS + pa];
       const int pixoff = (p >> g.lgW) * PC + (p & (g.W - 1));
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
@@ -151,18 +163,17 @@ __global__ __launch_bounds__(GMK_THIN_THREADS) void conv_wgrad_thin_kernel(const
         bsum += Tl[wave * PS + (PAD + (p >> g.lgW)) * PC + PAD + (p & (g.W - 1))];
       }
     }
-    if (ch + g.G < g.total_chunks) {
-      store_chunk(smem + ((it + 1) & 1) * tile_floats);  // last read two iterations ago: every wave has passed a barrier since
-      if (ch + 2 * (long long)g.G < g.total_chunks) load_chunk(ch + 2 * (long long)g.G);
-    }
-    __syncthreads();
   }
 
-  // combine the 8 waves' partials in LDS in wave order (fixed -> deterministic), then one slab per block
+  // combine the 8 waves' partials in LDS in a fixed order (deterministic): waves 0-3 store, waves 4-7 add onto
+  // them, the slab write sums the four regions as (R0+R1)+(R2+R3); one slab per block.
+  constexpr int RS = 64 * NCB;
   float* Red = smem;
 #pragma unroll 1
-  for (int w = 0; w < NT / 64; ++w) {
-    if (wave == w) {
+  for (int ph = 0; ph < 2; ++ph) {
+    __syncthreads();
+    if ((wave >> 2) == ph) {
+      float* R = Red + (wave & 3) * RS;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -171,38 +182,42 @@ __global__ __launch_bounds__(GMK_THIN_THREADS) void conv_wgrad_thin_kernel(const
           for (int r = 0; r < 16; ++r) {
             const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             const int idx = row * NCB + nb * 32 + jj;
-            Red[idx] = (w == 0) ? acc[i][nb][r] : Red[idx] + acc[i][nb][r];
+            R[idx] = (ph == 0) ? acc[i][nb][r] : R[idx] + acc[i][nb][r];
           }
     }
-    __syncthreads();
   }
+  __syncthreads();
   constexpr int SLAB = 64 * NCB + 64;
   float* out = g.slab + ((size_t)blockIdx.x * gridDim.y + wt) * (size_t)SLAB;
-  for (int e = tid; e < 64 * NCB; e += NT) out[e] = Red[e];
-  if (wave < 8) {
-    const float s = gmk_wave_sumf(bsum);
-    if (lane == 0) out[64 * NCB + wave] = s;
-  }
+  for (int e = tid; e < RS; e += NT) out[e] = (Red[e] + Red[RS + e]) + (Red[2 * RS + e] + Red[3 * RS + e]);
+  const float bs = gmk_wave_sumf(bsum);
+  if (lane == 0) out[RS + wave] = bs;
 }
 
-// dW / dbias from the slabs: fixed-order sum over the G blocks (8 interleaved partial sums, fixed tree).
+// dW / dbias from the slabs: fixed-order sum over the G blocks (32 interleaved partial sums per element,
+// combined by a fixed shuffle-free LDS tree).
 template <int KS, int NB>
-__global__ __launch_bounds__(256) void conv_wgrad_thin_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                                     float* __restrict__ dbias, const ThinGeom g) {
+__global__ __launch_bounds__(1024) void conv_wgrad_thin_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                                      float* __restrict__ dbias, const ThinGeom g) {
   constexpr int KK = KS * KS, NCB = 32 * NB, SLAB = 64 * NCB + 64;
-  __shared__ float red[8][32];
+  __shared__ float red[32][33];
   const int wt = blockIdx.y;
   const int el = threadIdx.x & 31, gq = threadIdx.x >> 5;
   const int e = blockIdx.x * 32 + el;
   float sum = 0.f;
   if (e < SLAB) {
-#pragma unroll 4
-    for (int gi = gq; gi < g.G; gi += 8) sum += slab[((size_t)gi * g.nWT + wt) * (size_t)SLAB + e];
+#pragma unroll 8
+    for (int gi = gq; gi < g.G; gi += 32) sum += slab[((size_t)gi * g.nWT + wt) * (size_t)SLAB + e];
   }
   red[gq][el] = sum;
   __syncthreads();
+#pragma unroll
+  for (int st = 16; st > 0; st >>= 1) {
+    if (gq < st) red[gq][el] += red[gq + st][el];
+    __syncthreads();
+  }
   if (gq != 0 || e >= SLAB) return;
-  sum = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) + ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
+  sum = red[0][el];
   if (e < 64 * NCB) {
     const int wc = wt * 64 + e / NCB, col = e % NCB;
     if (wc >= g.Cw) return;
@@ -227,9 +242,7 @@ static inline bool gmk_thin_plan(ThinGeom& g, int N, int Cw, int Ct, int H, int 
   g.N = N; g.Cw = Cw; g.Ct = Ct; g.H = H; g.W = W; g.lgW = gmk_ilog2(W); g.lgHW = gmk_ilog2((int64_t)H * W);
   g.total_chunks = ((long long)N * H * W) / GMK_THIN_PX;
   g.nWT = (Cw + 63) / 64;
-  long long want = 256 / g.nWT;
-  if (want < 16) want = 16;
-  g.G = (int)(g.total_chunks < want ? g.total_chunks : want);
+  g.G = (int)((g.total_chunks + GMK_THIN_CPB - 1) / GMK_THIN_CPB);
   g.sgn = sgn;
   g.PR = GMK_THIN_PX / W + ksize - 1; g.PC = W + ksize - 1; g.PS = g.PR * g.PC; g.npos = Ct * g.PS;
   if (g.npos > GMK_THIN_TSLOT * GMK_THIN_THREADS) return false;

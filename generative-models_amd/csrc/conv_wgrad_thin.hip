@@ -4,8 +4,9 @@
 template <int KS, int NB>
 static int launch_thin(ThinGeom& g, float* dw, float* dbias, hipStream_t s) {
   constexpr int SLAB = 64 * 32 * NB + 64;
-  const int tile_floats = 64 * (GMK_THIN_PX + 1) + ((g.npos + 3) & ~3);
-  const size_t lds = sizeof(float) * 2 * (size_t)tile_floats;
+  size_t lds = sizeof(float) * (64 * (size_t)GMK_THIN_SS + ((g.npos + 4) & ~3));
+  const size_t red = sizeof(float) * 4 * 64 * 32 * NB;  // 4 partial regions for the in-block reduction
+  if (lds < red) lds = red;
   if (lds > 160 * 1024) return GMK_E_SHAPE;
   auto kern = conv_wgrad_thin_kernel<KS, NB>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -13,7 +14,7 @@ static int launch_thin(ThinGeom& g, float* dw, float* dbias, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3(g.G, g.nWT), dim3(GMK_THIN_THREADS), lds, s, g);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((conv_wgrad_thin_reduce_kernel<KS, NB>), dim3((SLAB + 31) / 32, g.nWT), dim3(256), 0, s, g.slab, dw,
+  hipLaunchKernelGGL((conv_wgrad_thin_reduce_kernel<KS, NB>), dim3((SLAB + 31) / 32, g.nWT), dim3(1024), 0, s, g.slab, dw,
                      dbias, g);
   e = hipGetLastError();
   return e == hipSuccess ? GMK_OK : (int)e;

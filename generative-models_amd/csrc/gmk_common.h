@@ -108,6 +108,15 @@ __device__ __forceinline__ float gmk_buffer_load(__amdgpu_buffer_rsrc_t r, int v
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voffset_bytes, soffset_bytes, 0));
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global
+// load (s_waitcnt vmcnt(0)), which serialises register prefetch against the barrier; this one leaves
+// global loads in flight (the compiler still waits on a load's registers before their first use).
+__device__ __forceinline__ void gmk_lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // wave64 sum reduction (all lanes get the result in lane 0; use after per-thread partials)
 __device__ __forceinline__ double gmk_wave_sum(double v) {
 #pragma unroll
