@@ -91,6 +91,109 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
   }
 }
 
+// ---- pipelined variant: float4 global loads along each operand's contiguous axis, next K-chunk prefetched in
+// registers, double-buffered K-major LDS tiles (one LDS-only barrier per chunk, MFMA operand reads conflict-free).
+// Requires the contiguous extents to be multiples of 4 and 16-byte aligned bases (host checks); rows / K beyond the
+// problem are clamped for the load and zeroed on the way into LDS, so the loop is branch-free.
+#define GLD 68  // LDS row stride (floats) of a [GK][64] tile: 16-byte rows for ds_write_b128
+__global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float smem[2][2][GK * GLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
+  const int kbeg = blockIdx.z * g.kper;
+  const int kend = min(g.K, kbeg + g.kper);
+  const bool a_kfast = (g.sak == 1), b_kfast = (g.sbk == 1);
+  // per-thread quads: k-fast operand -> 8 quads per row (row = t/8 + 32u); row-fast operand -> 16 quads per k (k = t/16 + 16u)
+  const float* abase[2]; const float* bbase[2];
+  int a_k[2], b_k[2];      // first k (within the chunk) of the quad
+  int a_l[2], b_l[2];      // LDS offset of the quad's first element
+  bool a_ok[2], b_ok[2];   // row inside the matrix
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (a_kfast) {
+      const int r = tid / 8 + 32 * u, kq = tid % 8;
+      const int gi = i0 + r;
+      a_ok[u] = gi < g.M;
+      abase[u] = g.A + (long long)(a_ok[u] ? gi : g.M - 1) * g.sai;
+      a_k[u] = kq * 4; a_l[u] = kq * 4 * GLD + r;
+    } else {
+      const int k = tid / 16 + 16 * u, q = tid % 16;
+      const int gi = i0 + q * 4;
+      a_ok[u] = gi < g.M;
+      abase[u] = g.A + (a_ok[u] ? gi : 0);
+      a_k[u] = k; a_l[u] = k * GLD + q * 4;
+    }
+    if (b_kfast) {
+      const int r = tid / 8 + 32 * u, kq = tid % 8;
+      const int gj = j0 + r;
+      b_ok[u] = gj < g.N;
+      bbase[u] = g.B + (long long)(b_ok[u] ? gj : g.N - 1) * g.sbj;
+      b_k[u] = kq * 4; b_l[u] = kq * 4 * GLD + r;
+    } else {
+      const int k = tid / 16 + 16 * u, q = tid % 16;
+      const int gj = j0 + q * 4;
+      b_ok[u] = gj < g.N;
+      bbase[u] = g.B + (b_ok[u] ? gj : 0);
+      b_k[u] = k; b_l[u] = k * GLD + q * 4;
+    }
+  }
+  float4 ar[2], br[2];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_chunk = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int ka = k0 + a_k[u]; ka = ka < kend ? ka : kend - 4;  // clamped (kend % 4 == 0 for k-fast operands)
+      ar[u] = a_kfast ? *(const float4*)(abase[u] + ka) : *(const float4*)(abase[u] + (long long)min(k0 + a_k[u], kend - 1) * g.sak);
+      int kb = k0 + b_k[u]; kb = kb < kend ? kb : kend - 4;
+      br[u] = b_kfast ? *(const float4*)(bbase[u] + kb) : *(const float4*)(bbase[u] + (long long)min(k0 + b_k[u], kend - 1) * g.sbk);
+    }
+  };
+  auto store_chunk = [&](int k0, int buf) {
+    float* As = smem[buf][0];
+    float* Bs = smem[buf][1];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float4 a = (a_ok[u] && k0 + a_k[u] < kend) ? ar[u] : z4;
+      if (a_kfast) { float* d = As + a_l[u]; d[0] = a.x; d[GLD] = a.y; d[2 * GLD] = a.z; d[3 * GLD] = a.w; }
+      else *(float4*)(As + a_l[u]) = a;
+      const float4 b = (b_ok[u] && k0 + b_k[u] < kend) ? br[u] : z4;
+      if (b_kfast) { float* d = Bs + b_l[u]; d[0] = b.x; d[GLD] = b.y; d[2 * GLD] = b.z; d[3 * GLD] = b.w; }
+      else *(float4*)(Bs + b_l[u]) = b;
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  load_chunk(kbeg);
+  store_chunk(kbeg, 0);
+  int buf = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += GK, buf ^= 1) {
+    const bool more = k0 + GK < kend;  // uniform
+    if (more) load_chunk(k0 + GK);
+    gmk_lds_barrier();  // tile `buf` is complete; the other tile's readers (previous iteration) are done
+    const float* As = smem[buf][0];
+    const float* Bs = smem[buf][1];
+#pragma unroll
+    for (int s = 0; s < GK / 2; ++s) {
+      const float a = As[(2 * s + h) * GLD + wr * 32 + l31];
+      const float b = Bs[(2 * s + h) * GLD + wc * 32 + l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    if (more) store_chunk(k0 + GK, buf ^ 1);
+  }
+  const int j = j0 + wc * 32 + l31;
+  if (j >= g.N) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (i >= g.M) continue;
+    if (g.slab) g.slab[((size_t)blockIdx.z * g.M + i) * g.N + j] = acc[r];
+    else gemm_epilogue(g, i, j, acc[r]);
+  }
+}
+
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs g, int splits) {
   const size_t total = (size_t)g.M * g.N;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
@@ -100,24 +203,26 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs 
   }
 }
 
-// column sums: out[j] = sum_i t[i*N + j]  (bias gradient); one thread per column, fixed order
+// column sums: out[j] = sum_i t[i*N + j]  (bias gradient); 64 columns x 4 row groups per block, fixed order
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ t, float* __restrict__ out, int M, int N) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= N) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int i = 0;
-  for (; i + 3 < M; i += 4) {
-    s0 += t[(size_t)i * N + j]; s1 += t[(size_t)(i + 1) * N + j];
-    s2 += t[(size_t)(i + 2) * N + j]; s3 += t[(size_t)(i + 3) * N + j];
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
+  float s0 = 0.f, s1 = 0.f;
+  if (j < N) {
+    int i = q;
+    for (; i + 4 < M; i += 8) { s0 += t[(size_t)i * N + j]; s1 += t[(size_t)(i + 4) * N + j]; }
+    for (; i < M; i += 4) s0 += t[(size_t)i * N + j];
   }
-  for (; i < M; ++i) s0 += t[(size_t)i * N + j];
-  out[j] = (s0 + s1) + (s2 + s3);
+  red[q][c] = s0 + s1;
+  __syncthreads();
+  if (q == 0 && j < N) out[j] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
 static int pick_splits(int M, int N, int K) {
   const int tiles = ((M + GT - 1) / GT) * ((N + GT - 1) / GT);
   int splits = 1;
-  while (tiles * splits < 384 && K / (splits * 2) >= 128 && splits < 64) splits *= 2;
+  while (tiles * splits < 512 && K / (splits * 2) >= 128 && splits < 64) splits *= 2;
   return splits;
 }
 
@@ -144,7 +249,14 @@ static int run_gemm(GemmArgs g, void* ws, size_t ws_bytes, hipStream_t s) {
   } else {
     g.slab = nullptr;
   }
-  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, g);
+  // pipelined kernel when every float4 load is aligned: contiguous extents % 4 == 0, 16-byte bases and row pitches
+  const bool a_k = g.sak == 1, b_k = g.sbk == 1;
+  const bool a_fast = a_k ? (g.K % 4 == 0 && g.sai % 4 == 0) : (g.sai == 1 && g.M % 4 == 0 && g.sak % 4 == 0);
+  const bool b_fast = b_k ? (g.K % 4 == 0 && g.sbj % 4 == 0) : (g.sbj == 1 && g.N % 4 == 0 && g.sbk % 4 == 0);
+  if (a_fast && b_fast && gmk_aligned16(g.A) && gmk_aligned16(g.B) && g.K >= 4)
+    hipLaunchKernelGGL(gemm_f32_pipe_kernel, grid, dim3(256), 0, s, g);
+  else
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, g);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   if (zs > 1) {
@@ -191,7 +303,7 @@ extern "C" int gmk_linear_wgrad(const float* dy, const float* x, float* dw, floa
   int rc = run_gemm(g, ws, ws_bytes, (hipStream_t)stream);
   if (rc) return rc;
   if (dbias) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, dy, dbias, M, N);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, dy, dbias, M, N);
     GMK_CHECK_LAUNCH();
   }
   return GMK_OK;
