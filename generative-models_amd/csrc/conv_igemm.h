@@ -258,7 +258,7 @@ static int gmk_launch_conv_impl(ConvGeom& g, int mode, hipStream_t s) {
   // else 64 x 64; 32 x 128 when the op has <= 32 output channels (dec.conv3: 3).
   int WM, MT;
   if (g.M <= 32) { WM = 1; MT = 1; }
-  else if (mode != 2 && g.total_base / 128 >= 512) { WM = 1; MT = 2; }  // MODE2 keeps 4 parity accumulators
+  else if (mode != 2 && g.total_base / 128 >= 512 && !(g.dbg & 4)) { WM = 1; MT = 2; }  // MODE2 keeps 4 parity accumulators
   else { WM = 2; MT = 1; }
   const int WP = 4 / WM, PT = WP * 32, MB = WM * MT * 32;
   if (g.BW > PT) return GMK_E_SHAPE;

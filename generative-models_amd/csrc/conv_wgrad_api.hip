@@ -4,19 +4,19 @@
 
 static void wgrad_plan(WgradGeom& g, int N, int Cs, int Cb, int SH, int SW, int ksize, int sb) {
   g.N = N; g.Cs = Cs; g.Cb = Cb; g.SH = SH; g.SW = SW; g.BHt = SH * sb; g.BWt = SW * sb;
-  g.lgSW = gmk_ilog2(SW); g.lgSHW = gmk_ilog2((int64_t)SH * SW);
-  g.P = gmk_wgrad_chunk_px(SH, SW, sb); g.lgP = gmk_ilog2(g.P);
+  g.lgSW = gmk_ilog2(SW); g.lgSHW = gmk_ilog2((int64_t)SH * SW); g.lgBWt = gmk_ilog2(g.BWt);
+  g.P = gmk_wgrad_chunk_px(SH, SW, ksize, sb); g.lgP = gmk_ilog2(g.P);
   g.total_chunks = ((long long)N * SH * SW) / g.P;
-  g.csT = (Cs + 63) / 64; g.cbT = (Cb + 63) / 64;
+  g.csT = (Cs + GMK_WG_T - 1) / GMK_WG_T; g.cbT = (Cb + GMK_WG_T - 1) / GMK_WG_T;
   const int ntg = ksize == 3 ? 1 : ksize;
-  long long want = 256 / ((long long)g.csT * g.cbT * ntg);  // one block per CU: chunks are prefetched in registers
-  if (want < 32) want = 32;
+  long long want = 256 / ((long long)g.csT * g.cbT * ntg);  // one block per CU (144 accumulator + prefetch registers)
+  if (want < 16) want = 16;
   g.G = (int)(g.total_chunks < want ? g.total_chunks : want);
 }
 
 static size_t slab_bytes(const WgradGeom& g, int ksize) {
   const int KK = ksize * ksize, NT = ksize == 3 ? KK : ksize, NTG = KK / NT;
-  return sizeof(float) * (size_t)g.G * g.csT * g.cbT * NTG * (NT * 4096 + 64);
+  return sizeof(float) * (size_t)g.G * g.csT * g.cbT * NTG * gmk_wgrad_slab_floats(ksize);
 }
 
 static size_t wgrad_ws_bytes(int N, int Cs, int Cb, int SH, int SW, int ksize, int sb, int Cbias) {
@@ -45,7 +45,7 @@ extern "C" size_t gmk_deconv2d_wgrad_workspace_bytes(int N, int Cin, int H, int 
 static int wgrad_run(const float* small, const float* big, float* dw, float* dbias, int bias_mode, int N, int Cs,
                      int Cb, int SH, int SW, int ksize, int sb, void* ws, size_t ws_bytes, hipStream_t s) {
   if (ksize != 3 && ksize != 5) return GMK_E_UNSUPPORTED;
-  if (!gmk_is_pow2(SH) || !gmk_is_pow2(SW) || SW * sb > 128 || SH * SW < 16) return GMK_E_SHAPE;
+  if (!gmk_is_pow2(SH) || !gmk_is_pow2(SW) || SW * sb > 128 || SH * SW < 32) return GMK_E_SHAPE;
   if (!gmk_aligned16(ws)) return GMK_E_ALIGN;
   WgradGeom g{};
   wgrad_plan(g, N, Cs, Cb, SH, SW, ksize, sb);
