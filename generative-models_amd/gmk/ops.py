@@ -27,13 +27,56 @@ def _chk(*ts):
 
 
 def workspace(nbytes, device):
-    """A cached per-device byte workspace (grown on demand; single stream use)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    """A cached byte workspace per (device, current stream), grown on demand: kernels of one stream run in
+    order, so they can share scratch; two streams (the wgrad side queue) must not."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
     return ws
+
+
+class SideQueue:
+    """Runs independent work (the weight-gradient kernels of backward) on a second HIP stream so that it
+    overlaps the dgrad chain on the main stream: the two kinds of kernel fill each other's prologue /
+    epilogue / tail bubbles.  Tensors read on the side stream are kept alive until join() has ordered the
+    main stream behind it (the caching allocator would otherwise hand their memory to later main-stream work)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.stream = torch.cuda.Stream(device)
+        self._keep = []
+
+    def run(self, fn, *tensors):
+        """fn() is enqueued on the side stream after everything enqueued so far on the current stream."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.stream.wait_event(ev)
+        self._keep.extend(tensors)
+        with torch.cuda.stream(self.stream):
+            return fn()
+
+    def join(self):
+        """The current stream waits for all side work; kept tensors may be freed afterwards."""
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        self._keep.clear()
+
+
+_side_cache = {}
+
+
+def side_queue(device):
+    """The process-wide wgrad side queue of `device` (GMK_SIDE_WGRAD=0 disables it: one stream for everything)."""
+    import os
+    if os.environ.get("GMK_SIDE_WGRAD", "1") == "0":
+        return None
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    q = _side_cache.get(key)
+    if q is None:
+        q = _side_cache[key] = SideQueue(torch.device("cuda", key))
+    return q
 
 
 def conv2d_fwd(x, w, bias, stride=1, act=None, want_dact=False):

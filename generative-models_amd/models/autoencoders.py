@@ -13,6 +13,8 @@ There is no PyTorch fallback: CPU tensors or a missing libgmk.so raise.
 Besides the drop-in autograd path (`recon = model(image)` then any loss), `train_step()` runs the
 whole step (forward, fused sigmoid+MSE+KL loss kernel, backward) without autograd bookkeeping.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -275,16 +277,28 @@ class Autoencoder(nn.Module):
                                           no_upsample=dec.no_upsample, interpolation=dec.interpolation,
                                           ksize=dec.kernel_size, base=dec.base, train=True, final_act=None)
         losses, dpre, dstats, _ = ops.vae_loss_fwd_bwd(pre, image, stats, beta, sigmoid=sigmoid, mse_prior=mse_prior)
+        # weight gradients run on a side stream, overlapping the dgrad chain on this one (gmk.ops.SideQueue)
+        side = ops.side_queue(image.device)
+
+        def bucket_ready(name):
+            if reducer is None:
+                return
+            if side is None:
+                reducer.ready(name)
+            else:  # the bucket's gradients are ordered on the side stream: the all-reduce waits for that stream
+                with torch.cuda.stream(side.stream):
+                    reducer.ready(name)
+
         _, dz = engine.decoder_backward(pd, svd, dpre, no_upsample=dec.no_upsample, interpolation=dec.interpolation,
-                                        ksize=dec.kernel_size, need_dz=True, gout=gd)
-        if reducer is not None:
-            reducer.ready("decoder")
+                                        ksize=dec.kernel_size, need_dz=True, gout=gd, side=side)
+        bucket_ready("decoder")
         if self.variational:
             dout = ops.reparam_bwd(dz, stats, eps, dstats=dstats).view(B, -1)
         else:
             dout = dz
         engine.encoder_backward(pe, sve, dout, no_pool=enc.no_pool, ksize=enc.kernel_size, gout=ge,
-                                on_fc_done=(lambda: reducer.ready("encoder.fc")) if reducer is not None else None)
-        if reducer is not None:
-            reducer.ready("encoder.conv")
+                                on_fc_done=lambda: bucket_ready("encoder.fc"), side=side)
+        bucket_ready("encoder.conv")
+        if side is not None:
+            side.join()
         return losses
