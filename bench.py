@@ -64,9 +64,20 @@ def dominant_kernel_roofline(device, iters=30):
     t = e0.elapsed_time(e1) * 1e-3 / iters
     flops = 2.0 * N * H * H * C * C * 9
     ach = flops / t / 1e12
+    # HBM bytes per launch of this kernel/shape from the committed PMC passes (FETCH_SIZE doubled as the gfx950
+    # guide prescribes, + WRITE_SIZE; tools/prof_targets.py + tools/pmc_summary.py), null if the file is absent
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+            for row in json.load(f):
+                if row["kernel"].startswith("void conv_igemm_kernel<0, 3, 8, 1, 2, 1>") and "hbm_read_B" in row:
+                    traffic = round(row["hbm_read_B"] + row["hbm_write_B"])
+    except (OSError, ValueError, KeyError):
+        traffic = None
     return {"kernel": "conv_igemm_kernel<S1,k3,64->64,16x16,B256>", "bound": "mfma", "achieved": round(ach, 2),
             "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-            "launch_us": round(t * 1e6, 2), "flops_per_launch": flops, "traffic": None}
+            "launch_us": round(t * 1e6, 2), "flops_per_launch": flops, "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_summary.json)"}
 
 
 def cpu_baseline(steps=6):
