@@ -181,67 +181,85 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
   }
 
   // ---- epilogue ----
-  // Accumulator layout (rows = pixels, cols = channels): lane -> channel (lane & 31); register r ->
-  // pixel (r & 3) + 8 (r >> 2) + 4 h of the wave's 32-pixel tile, i.e. every register quad holds 4
-  // consecutive pixels of one channel plane: 16-byte stores / loads, one bias value per lane.
+  // Accumulator layout (rows = pixels, cols = channels): lane -> channel (lane & 31); register r -> pixel
+  // (r & 3) + 8 (r >> 2) + 4 h of the wave's 32-pixel tile.  Stored like that every lane would write 16-byte
+  // pieces of 32 different channel planes per instruction (partial cache lines; MODE 2: 80 of 140 us).  So each
+  // wave transposes its tile through LDS ([channel][NPX output floats] rows) and then stores whole 128-byte
+  // rows: NPX/4 lanes cover one channel row with 16 bytes each, 64/(NPX/4) channels per instruction.
+  // Bias, activation (+ act') and the act' multiply of dgrad are applied on the way out.
+  constexpr int NPX = (MODE == 2) ? 64 : 32;   // output floats per channel, wave and pass (MODE 2: one row parity)
+  constexpr int ES = NPX + 4;                  // LDS row stride (16-byte rows)
+  constexpr int QPR = NPX / 4;                 // float4 quads per row
+  constexpr int CPI = 64 / QPR;                // channels per store instruction
+  float* Ew = smem + wave * 32 * ES;
   if ((g.dbg & 1) && acc[0][0][0] != 12345.678f) return;
+  const int eq = lane % QPR, ec = lane / QPR;
+  // position of this lane's quad: MODE 0/1: 4 output pixels = base positions 4eq..4eq+3 ; MODE 2: 4 output floats
+  // = base positions 2eq, 2eq+1 (x parity interleaved)
+  const long long Pq = p0 + wp * 32 + ((MODE == 2) ? 2 * eq : 4 * eq);
+  const bool pok = Pq < g.total_base;
+  const long long nq = Pq >> g.lgBHW;
+  const int remq = (int)(Pq & (BHW - 1));
+  const int byq = remq >> g.lgBW, bxq = remq & (g.BW - 1);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int m = m0 + (wm * MT + i) * 32 + j;
-    if (m >= g.M) continue;
-    const float bv = (g.epi == 0 && g.bias) ? g.bias[m] : 0.f;
 #pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) {
-      const long long P = p0 + wp * 32 + 8 * k4 + 4 * h;  // first of 4 consecutive base positions
-      if (P >= g.total_base) continue;
-      const long long n = P >> g.lgBHW;
-      const int rem = (int)(P & (BHW - 1));
-      if (MODE != 2) {
-        const long long idx = (n * g.M + m) * (long long)BHW + rem;
-        float4 v = make_float4(acc[0][i][4 * k4], acc[0][i][4 * k4 + 1], acc[0][i][4 * k4 + 2], acc[0][i][4 * k4 + 3]);
-        if (g.epi == 0) {
-          float4 a, d;
-          gmk_act_fwd(g.act, v.x + bv, a.x, d.x);
-          gmk_act_fwd(g.act, v.y + bv, a.y, d.y);
-          gmk_act_fwd(g.act, v.z + bv, a.z, d.z);
-          gmk_act_fwd(g.act, v.w + bv, a.w, d.w);
-          *(float4*)(g.y + idx) = a;
-          if (g.dact_out) *(float4*)(g.dact_out + idx) = d;
+    for (int py = 0; py < ((MODE == 2) ? 2 : 1); ++py) {
+      __syncthreads();  // main-loop LDS reads / the previous pass's reads are done
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        if (MODE != 2) {
+          *(float4*)(Ew + j * ES + 8 * k4 + 4 * h) =
+              make_float4(acc[0][i][4 * k4], acc[0][i][4 * k4 + 1], acc[0][i][4 * k4 + 2], acc[0][i][4 * k4 + 3]);
         } else {
-          if (g.dact_in) {
-            const float4 dd = *(const float4*)(g.dact_in + idx);
-            v.x *= dd.x; v.y *= dd.y; v.z *= dd.z; v.w *= dd.w;
-          }
-          *(float4*)(g.y + idx) = v;
-        }
-      } else {
-        const int by = rem >> g.lgBW, bxx = rem & (g.BW - 1);
-#pragma unroll
-        for (int py = 0; py < 2; ++py) {
-          const long long idx = (n * g.M + m) * (long long)(4 * BHW) + (long long)(2 * by + py) * (2 * g.BW) + 2 * bxx;
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { v[2 * e] = acc[py * 2][i][4 * k4 + e]; v[2 * e + 1] = acc[py * 2 + 1][i][4 * k4 + e]; }
-          if (g.epi == 0) {
-            float a[8], d[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) gmk_act_fwd(g.act, v[e] + bv, a[e], d[e]);
-            *(float4*)(g.y + idx) = make_float4(a[0], a[1], a[2], a[3]);
-            *(float4*)(g.y + idx + 4) = make_float4(a[4], a[5], a[6], a[7]);
-            if (g.dact_out) {
-              *(float4*)(g.dact_out + idx) = make_float4(d[0], d[1], d[2], d[3]);
-              *(float4*)(g.dact_out + idx + 4) = make_float4(d[4], d[5], d[6], d[7]);
-            }
-          } else {
-            if (g.dact_in) {
-              const float4 d0 = *(const float4*)(g.dact_in + idx), d1 = *(const float4*)(g.dact_in + idx + 4);
-              v[0] *= d0.x; v[1] *= d0.y; v[2] *= d0.z; v[3] *= d0.w; v[4] *= d1.x; v[5] *= d1.y; v[6] *= d1.z; v[7] *= d1.w;
-            }
-            *(float4*)(g.y + idx) = make_float4(v[0], v[1], v[2], v[3]);
-            *(float4*)(g.y + idx + 4) = make_float4(v[4], v[5], v[6], v[7]);
-          }
+          float* d = Ew + j * ES + 16 * k4 + 8 * h;
+          *(float4*)d = make_float4(acc[py * 2][i][4 * k4], acc[py * 2 + 1][i][4 * k4], acc[py * 2][i][4 * k4 + 1],
+                                    acc[py * 2 + 1][i][4 * k4 + 1]);
+          *(float4*)(d + 4) = make_float4(acc[py * 2][i][4 * k4 + 2], acc[py * 2 + 1][i][4 * k4 + 2],
+                                          acc[py * 2][i][4 * k4 + 3], acc[py * 2 + 1][i][4 * k4 + 3]);
         }
       }
+      __syncthreads();
+      // bias of this lane's channels, fetched before the math (one L1-resident load per store instruction)
+      float bvs[32 / CPI];
+#pragma unroll
+      for (int it = 0; it < 32 / CPI; ++it) {
+        const int m = m0 + (wm * MT + i) * 32 + ec + it * CPI;
+        bvs[it] = (g.epi == 0 && g.bias && m < g.M) ? g.bias[m] : 0.f;
+      }
+      // the activation switch is hoisted out of the store loop: GELU (the reference default) and identity
+      // get straight-line code, the other activations share the generic switch
+      auto store_rows = [&](auto actf) {
+#pragma unroll
+        for (int it = 0; it < 32 / CPI; ++it) {
+          const int c = ec + it * CPI;
+          const int m = m0 + (wm * MT + i) * 32 + c;
+          if (m >= g.M || !pok) continue;
+          float4 v = *(const float4*)(Ew + c * ES + 4 * eq);
+          long long idx;
+          if (MODE != 2) idx = (nq * g.M + m) * (long long)BHW + remq;
+          else idx = (nq * g.M + m) * (long long)(4 * BHW) + (long long)(2 * byq + py) * (2 * g.BW) + 2 * bxq;
+          if (g.epi == 0) {
+            const float bv = bvs[it];
+            float4 a, d;
+            actf(v.x + bv, a.x, d.x);
+            actf(v.y + bv, a.y, d.y);
+            actf(v.z + bv, a.z, d.z);
+            actf(v.w + bv, a.w, d.w);
+            *(float4*)(g.y + idx) = a;
+            if (g.dact_out) *(float4*)(g.dact_out + idx) = d;
+          } else {
+            if (g.dact_in) {
+              const float4 dd = *(const float4*)(g.dact_in + idx);
+              v.x *= dd.x; v.y *= dd.y; v.z *= dd.z; v.w *= dd.w;
+            }
+            *(float4*)(g.y + idx) = v;
+          }
+        }
+      };
+      if (g.epi != 0 || g.act == GMK_ACT_NONE) store_rows([](float z, float& a, float& d) { a = z; d = 1.f; });
+      else if (g.act == GMK_ACT_GELU) store_rows([](float z, float& a, float& d) { gmk_gelu_fwd(z, a, d); });
+      else store_rows([&](float z, float& a, float& d) { gmk_act_fwd(g.act, z, a, d); });
     }
   }
 }
@@ -258,7 +276,7 @@ static int gmk_launch_conv_impl(ConvGeom& g, int mode, hipStream_t s) {
   // else 64 x 64; 32 x 128 when the op has <= 32 output channels (dec.conv3: 3).
   int WM, MT;
   if (g.M <= 32) { WM = 1; MT = 1; }
-  else if (mode != 2 && g.total_base / 128 >= 512 && !(g.dbg & 4)) { WM = 1; MT = 2; }  // MODE2 keeps 4 parity accumulators
+  else if (mode != 2 && g.total_base / 128 >= 512) { WM = 1; MT = 2; }  // MODE2 keeps 4 parity accumulators (8 spill)
   else { WM = 2; MT = 1; }
   const int WP = 4 / WM, PT = WP * 32, MB = WM * MT * 32;
   if (g.BW > PT) return GMK_E_SHAPE;
@@ -275,7 +293,9 @@ static int gmk_launch_conv_impl(ConvGeom& g, int mode, hipStream_t s) {
   g.npos = g.nseg * g.PR * g.PC;
   if (g.npos > 256 * (mode == 1 ? 4 : 2)) return GMK_E_SHAPE;
   (void)BH;
-  const size_t lds = sizeof(float) * ((size_t)MB * ((CK * KK) | 1) + (size_t)g.nseg * CK * g.PS);
+  size_t lds = sizeof(float) * ((size_t)MB * ((CK * KK) | 1) + (size_t)g.nseg * CK * g.PS);
+  const size_t lds_epi = sizeof(float) * 4 * 32 * ((mode == 2 ? 64 : 32) + 4);  // per-wave transpose tiles of the epilogue
+  if (lds < lds_epi) lds = lds_epi;
   if (lds > 160 * 1024) return GMK_E_SHAPE;
   dim3 grid((unsigned)((g.total_base + PT - 1) / PT), (unsigned)((g.M + MB - 1) / MB));
   const int nslot = (g.npos + 255) / 256;

@@ -32,6 +32,23 @@ static inline bool gmk_aligned16(const void* p) { return (((uintptr_t)p) & 15u) 
 // (reference: /root/reference/utils.py:49-66)
 __device__ __forceinline__ float gmk_sigmoidf(float z) { return 1.0f / (1.0f + expf(-z)); }
 
+// exact-erf GELU and its derivative from ONE exponential and ONE reciprocal: e = exp(-z^2/2) serves both the pdf
+// and erfc(|z|/sqrt2) = P(t) e, t = 1/(1 + p |z|/sqrt2)  (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7; the 0.5 of
+// the cdf is folded into the coefficients).  v_exp_f32 / v_rcp_f32 are used directly (1 ulp).
+__device__ __forceinline__ void gmk_gelu_fwd(float z, float& a, float& d) {
+  const float az = fabsf(z);
+  const float e = __builtin_amdgcn_exp2f(z * z * -0.72134752044448170368f);          // exp(-z^2/2)
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, az, 1.0f));
+  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+  p = fmaf(p, t, 0.5f * 1.421413741f);
+  p = fmaf(p, t, 0.5f * -0.284496736f);
+  p = fmaf(p, t, 0.5f * 0.254829592f);
+  const float q = p * t * e;                    // 0.5 * erfc(|z|/sqrt2)
+  const float cdf = 0.5f + copysignf(0.5f - q, z);
+  a = z * cdf;
+  d = fmaf(z * 0.39894228040143267794f, e, cdf);
+}
+
 __device__ __forceinline__ void gmk_act_fwd(int act, float z, float& a, float& d) {
   switch (act) {
     case GMK_ACT_RELU:
@@ -55,22 +72,9 @@ __device__ __forceinline__ void gmk_act_fwd(int act, float z, float& a, float& d
       d = sc * (z > 0.f ? 1.f : al * (e + 1.f));
       break;
     }
-    case GMK_ACT_GELU: {
-      // exact-erf GELU and its derivative from ONE exponential: e = exp(-z^2/2) serves both the pdf and
-      // erf(z/sqrt2) = sign(z) (1 - P(t) e), t = 1/(1 + p |z|/sqrt2)  (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7)
-      const float ax = fabsf(z) * 0.70710678118654752440f;
-      const float e = __expf(-ax * ax);
-      const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
-      float p = fmaf(1.061405429f, t, -1.453152027f);
-      p = fmaf(p, t, 1.421413741f);
-      p = fmaf(p, t, -0.284496736f);
-      p = fmaf(p, t, 0.254829592f);
-      const float q = 0.5f * p * t * e;          // 0.5 * erfc(|z|/sqrt2)
-      const float cdf = z >= 0.f ? 1.0f - q : q;
-      a = z * cdf;
-      d = fmaf(z * 0.39894228040143267794f, e, cdf);
+    case GMK_ACT_GELU:
+      gmk_gelu_fwd(z, a, d);
       break;
-    }
     case GMK_ACT_SILU: {
       float s = 1.0f / (1.0f + expf(-z));
       a = z * s;
