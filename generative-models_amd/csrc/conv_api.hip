@@ -5,6 +5,11 @@
 #include "conv_igemm.h"
 #include <stdlib.h>
 
+// conv_thin_out.hip: forward of stride-1 convs with <= 8 output channels (dec.conv3)
+bool gmk_thin_out_ok(int N, int Cin, int H, int W, int Cout, int ksize, int stride);
+int gmk_launch_conv_thin_out(const float* x, const float* w, const float* bias, float* y, float* dact, int N, int Cin,
+                             int H, int W, int Cout, int ksize, int act, hipStream_t s);
+
 static int conv_common_checks(int N, int Cin, int H, int W, int Cout, int ksize) {
   if (N <= 0 || Cin <= 0 || Cout <= 0) return GMK_E_SHAPE;
   if (!gmk_is_pow2(H) || !gmk_is_pow2(W) || H < 4 || W < 4 || W > 128) return GMK_E_SHAPE;
@@ -25,6 +30,8 @@ extern "C" int gmk_conv2d_fwd(const float* x, const float* w, const float* bias,
   if (rc) return rc;
   GMK_REQUIRE(stride == 1 || stride == 2, GMK_E_UNSUPPORTED);
   GMK_REQUIRE(act >= GMK_ACT_NONE && act <= GMK_ACT_SIGMOID, GMK_E_UNSUPPORTED);
+  if (gmk_thin_out_ok(N, Cin, H, W, Cout, ksize, stride))
+    return gmk_launch_conv_thin_out(x, w, bias, y, dact, N, Cin, H, W, Cout, ksize, act, (hipStream_t)stream);
   const int KK = ksize * ksize;
   ConvGeom g{};
   g.x = x; g.w = w; g.bias = bias; g.dact_in = nullptr; g.y = y; g.dact_out = dact;

@@ -59,6 +59,11 @@ CONV_SHAPES = [
     (1, 1, 16, 16, 4, 3, 1),
     (200, 3, 32, 32, 64, 3, 1),
     (200, 32, 32, 32, 3, 3, 1),
+    # thin-output forward kernel (conv_thin_out.hip): ragged / >64 input channels, k=5 (3 column tiles), 64x64, 16x16
+    (2, 70, 32, 32, 3, 3, 1),
+    (2, 16, 32, 32, 3, 5, 1),
+    (1, 24, 64, 64, 2, 3, 1),
+    (3, 8, 16, 16, 1, 3, 1),
 ]
 
 
