@@ -88,3 +88,49 @@ def ae_params(tag, **cfg):
 
 def images(tag, n, hw=32):
     return uniform(f"{tag}/images", (n, 3, hw, hw), 0.0, 1.0)
+
+
+def classifier_param_shapes(latent_size):
+    """state_dict key -> shape of the reference Classifier, in registration order
+    (/root/reference/models/classifiers.py:15-26)."""
+    L = latent_size
+    s = {}
+    s["conv1.weight"] = (64, 3, 5, 5); s["conv1.bias"] = (64,)
+    s["conv2.weight"] = (128, 64, 5, 5); s["conv2.bias"] = (128,)
+    s["conv3.weight"] = (256, 128, 3, 3); s["conv3.bias"] = (256,)
+    s["fc.weight"] = (L, 256 * 4 * 4); s["fc.bias"] = (L,)
+    s["fc_out.weight"] = (10, L); s["fc_out.bias"] = (10,)
+    for name, c in (("bn1", 64), ("bn2", 128), ("bn3", 256), ("bn4", L)):
+        s[name + ".weight"] = (c,); s[name + ".bias"] = (c,)
+        s[name + ".running_mean"] = (c,); s[name + ".running_var"] = (c,)
+        s[name + ".num_batches_tracked"] = ()
+    return s
+
+
+def classifier_params(tag, latent_size):
+    """Deterministic Classifier state_dict: conv/linear like PyTorch's default init, BatchNorm with non-trivial
+    affine parameters and running statistics (so that eval-mode folding is actually exercised)."""
+    shapes = classifier_param_shapes(latent_size)
+    out = {}
+    for key, shp in shapes.items():
+        mod, leaf = key.rsplit(".", 1)
+        if mod.startswith("bn"):
+            if leaf == "weight":
+                out[key] = uniform(f"{tag}/{key}", shp, 0.5, 1.5)
+            elif leaf == "bias":
+                out[key] = uniform(f"{tag}/{key}", shp, -0.2, 0.2)
+            elif leaf == "running_mean":
+                out[key] = uniform(f"{tag}/{key}", shp, -0.1, 0.1)
+            elif leaf == "running_var":
+                out[key] = uniform(f"{tag}/{key}", shp, 0.5, 1.5)
+            else:
+                out[key] = np.array(7, dtype=np.int64)
+        else:
+            fan_in = int(np.prod(shapes[mod + ".weight"][1:]))
+            b = 1.0 / np.sqrt(fan_in)
+            if mod == "fc":
+                b *= 6.0    # spread the features / logits out so that the metrics are not degenerate
+            if mod == "fc_out":
+                b *= 25.0
+            out[key] = uniform(f"{tag}/{key}", shp, -b, b)
+    return out

@@ -29,9 +29,10 @@ sys.path.insert(0, REF)
 import metrics as ref_metrics                      # noqa: E402  /root/reference/metrics.py
 from models.autoencoders import Autoencoder as RefAutoencoder  # noqa: E402
 from utils import get_activation_function as ref_get_act       # noqa: E402
+from models.classifiers import Classifier as RefClassifier      # noqa: E402
 sys.path.remove(REF)
 
-from oracle import detgen, ae_oracle, metrics_oracle  # noqa: E402
+from oracle import detgen, ae_oracle, metrics_oracle, classifier_oracle  # noqa: E402
 
 torch.set_num_threads(8)
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -278,7 +279,50 @@ def gen_metrics():
         json.dump(out, f, indent=1)
 
 
+def gen_classifier():
+    """Eval-mode forward of the reference Classifier (models/classifiers.py:10-65) on deterministic weights, and the
+    reference metrics (metrics.py) driven by it: what main.compute_metrics does with the classifier (main.py:117-119)."""
+    out = {}
+    for act, L in (("gelu", 64), ("relu", 256)):
+        args = types.SimpleNamespace(debug=False, latent_size=L, dropout=0.5, act_fn=ref_get_act(act))
+        m = RefClassifier(args=args)
+        params = detgen.classifier_params(f"clf/{act}{L}", L)
+        sd = {k: torch.from_numpy(np.asarray(v).copy()) for k, v in params.items()}
+        assert list(m.state_dict().keys()) == list(sd.keys()), (list(m.state_dict().keys()), list(sd.keys()))
+        m.load_state_dict(sd)
+        m.eval()
+        x = torch.from_numpy(detgen.images(f"clf/{act}{L}/x", 8))
+        with torch.no_grad():
+            logits = m(x)
+            latent = m.latent_vector
+        o_logits, o_latent = classifier_oracle.classifier_forward({k: v for k, v in sd.items()}, x, act)
+        assert (o_logits - logits).abs().max() <= 1e-5 * logits.abs().max(), (o_logits - logits).abs().max()
+        assert (o_latent - latent).abs().max() <= 1e-5 * latent.abs().max()
+        case = dict(act=act, latent_size=L, n=8, logits=[float(v) for v in logits.reshape(-1)],
+                    latent_sample=sample(latent), latent_l2=l2(latent))
+        # metrics through the reference functions with this classifier (N >= latent_size for a full-rank covariance
+        # is not required by the reference's compute_fid itself; main.py:146-150 enforces it for its own batches)
+        n = 96 if L == 64 else 320
+        im1 = torch.from_numpy(detgen.images(f"clf/{act}{L}/im1", n))
+        im2 = torch.from_numpy(smooth_images(f"clf/{act}{L}/im2", n))
+        with torch.no_grad():
+            case["fid"] = float(ref_metrics.compute_fid(model=m, images1=im1, images2=im2))
+            case["inception_score"] = float(ref_metrics.compute_inception_score(m, im2))
+            conf, div = ref_metrics.compute_confidence_diversity(m, im2)
+            case["confidence"], case["diversity"] = float(conf), float(div)
+        case["n_metrics"] = n
+        print(f"classifier {act} L={L}: logits l2 {l2(logits):.5f} fid {case['fid']:.5f} IS {case['inception_score']:.5f} "
+              f"conf {case['confidence']:.4f} div {case['diversity']:.4f}")
+        out[f"{act}_L{L}"] = case
+    with open(os.path.join(OUT, "classifier.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "classifier":
+        gen_classifier()
+        raise SystemExit
     gen_train()
     gen_metrics()
+    gen_classifier()
     print("goldens written to", OUT)
