@@ -38,6 +38,7 @@ SIGNATURES = {
     "gmk_upsample2_fwd": (_I, [_P, _P, _L, _I, _I, _I, _P]),
     "gmk_upsample2_bwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
     "gmk_ew_mul": (_I, [_P, _P, _P, _L, _P]),
+    "gmk_cifar_batch": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _I, C.c_uint64, _P]),
     "gmk_adamw_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P]),
     "gmk_gram_workspace_bytes": (_Z, [_L, _I]),
     "gmk_gram_accumulate": (_I, [_P, _L, _I, _P, _P, _P, _Z, _P]),

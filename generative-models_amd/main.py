@@ -100,8 +100,11 @@ def main(args):
         raise SystemExit('this build runs on MI355X GPUs only (libgmk has no CPU path)')
     device = torch.device('cuda', local)
 
+    # GPU-resident feeder: the dataset stays in HBM as uint8, batches are assembled (gather + crop + flip + /255) by one
+    # kernel launch; with world > 1 every rank iterates its own shard of a shared epoch permutation
     train_dataloader, test_dataloader = get_cifar(data_dir=args.data_dir, train_batch_size=args.train_batch_size,
-                                                  test_batch_size=args.test_batch_size)
+                                                  test_batch_size=args.test_batch_size, device=device, rank=rank,
+                                                  world=world)
     if os.path.isfile('data/train_examples.pth') and os.path.isfile('data/test_examples.pth'):
         train_input_images = torch.load('data/train_examples.pth')
         test_input_images = torch.load('data/test_examples.pth')

@@ -57,7 +57,7 @@ def plot_grid(model, input_images=None, name=''):
     model.eval()
     with torch.no_grad():
         reconstructed_images = model(input_images.to(next(model.parameters()).device))
-    stack = torch.stack([input_images, reconstructed_images.cpu()], dim=1).flatten(0, 1)
+    stack = torch.stack([input_images.cpu(), reconstructed_images.cpu()], dim=1).flatten(0, 1)
     save_image_grid(stack, f'plots/{name}.png', nrow=input_images.shape[0], normalize=True)
 
 

@@ -158,6 +158,18 @@ int gmk_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, floa
                    float beta2, float eps, float weight_decay, int64_t step, float gscale,
                    gmk_stream_t stream);
 
+/* ---------------------------------------------------------------- data feeder -----------
+ * gmk_cifar_batch: out[b] = ToTensor(data[index[b]]) (uint8 -> fp32 / 255), and when `augment` != 0 the reference's
+ *   train transform RandomCrop(H, padding=pad) + RandomHorizontalFlip on top: per sample b,
+ *   h = mix32(mix32(b * 0x9E3779B1 + lo32(seed)) + hi32(seed) * 0x85EBCA6B)  (mix32 = lowbias32),
+ *   dy = h % (2 pad + 1), dx = (h >> 8) % (2 pad + 1), flip = (h >> 16) & 1,
+ *   out[b][c][y][x] = data[index[b]][c][y + dy - pad][(flip ? W-1-x : x) + dx - pad]  (0 outside the image).
+ *   replaces torchvision's CIFAR10 + transforms + DataLoader, /root/reference/dataloaders.py:23-41 (the dataset
+ *   stays resident in HBM as uint8; the host only supplies the shuffled index and a seed per batch).
+ *   data (n,C,H,W) uint8, index (B) int64, out (B,C,H,W) fp32; W % 4 == 0. */
+int gmk_cifar_batch(const unsigned char* data, const int64_t* index, float* out, int64_t B, int C, int H, int W,
+                    int pad, int augment, uint64_t seed, gmk_stream_t stream);
+
 /* ---------------------------------------------------------------- FID / inception stats --
  * gmk_gram_accumulate: n fp32 feature rows X (n, D) -> G (D,D) += X^T X, s (D) += column sums, both
  *   fp64, on v_mfma_f64_16x16x4_f64 (products of fp32 values are exact in fp64, so the moments do
