@@ -5,6 +5,7 @@ import torch
 import torch.nn.functional as F
 
 from helpers import case_inputs, check_against_golden, sample
+from oracle import detgen
 
 pytestmark = pytest.mark.gpu
 
@@ -92,3 +93,36 @@ def test_cpu_tensor_fails_loudly(train_golden):
     m = build(case, params)
     with pytest.raises((ValueError, RuntimeError)):
         m.cpu()(torch.from_numpy(x))
+
+
+@pytest.mark.parametrize("interp,B", [("nearest", 3), ("bilinear", 2)])
+def test_cfg5_pool_upsample_latent512_64x64_matches_oracle(interp, B):
+    """BASELINE.json configs[4]: VAE with pool + upsample layers, latent_size 512, 3x64x64 inputs.  The reference cannot
+    run it (8*8*num_channels is hard-coded, autoencoders.py:41,81,96: RuntimeError on 64x64), so there is no reference
+    golden: PARITY UNPINNED beyond the CPU oracle, which is itself pinned against the reference at 32x32 with the same
+    pool / upsample layers (vae_pool_* goldens).  Tolerance: BASELINE's 1e-4 relative on loss and per-tensor gradients."""
+    from oracle import ae_oracle
+    from models.autoencoders import Autoencoder
+    from utils import get_activation_function
+    shape = dict(variational=True, latent_size=512, num_channels=64, kernel_size=3, no_pool=False, no_upsample=False)
+    tag = f"cfg5/{interp}"
+    params = detgen.ae_params(tag, base=16, **shape)
+    x = detgen.images(tag, B, 64)
+    eps = detgen.normal(tag + "/eps", (B, 512))
+    m = Autoencoder(variational=True, latent_size=512, num_channels=64, kernel_size=3, act=get_activation_function("gelu"),
+                    sigmoid=True, interpolation=interp, no_pool=False, no_upsample=False, device="cuda:0", image_size=64)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    m = m.to("cuda:0")
+    losses = m.train_step(torch.from_numpy(x).cuda(), beta=5e-6, eps=torch.from_numpy(eps).cuda()).cpu().double()
+    cfg = dict(variational=True, latent_size=512, num_channels=64, act="gelu", sigmoid=True, no_pool=False,
+               no_upsample=False, interpolation=interp, kernel_size=3, base=16)
+    # fp64 run of the oracle: at 64x64 an fp32 CPU run flips one near-tied max-pool arg-max (1.7e-3 on the conv1 / conv2
+    # gradients against its own fp64 run), the kernels agree with fp64 to 1e-6
+    o = ae_oracle.train_step_grads(params, x, eps, 5e-6, cfg, dtype=torch.float64)
+    assert abs(float(losses[2]) - float(o["total"])) <= 1e-4 * abs(float(o["total"]))
+    assert abs(float(losses[1]) - float(o["kl"])) <= 1e-4 * abs(float(o["kl"]))
+    for k, p in m.named_parameters():
+        ref = o["grads"][k].numpy().astype(np.float64)
+        got = p.grad.cpu().numpy().astype(np.float64)
+        err = np.sqrt(((got - ref) ** 2).sum()) / max(np.sqrt((ref ** 2).sum()), 1e-30)
+        assert err <= 1e-4, (k, err)
