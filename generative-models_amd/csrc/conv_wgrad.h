@@ -11,6 +11,17 @@
 // four partial tiles are summed through LDS in a fixed order and ONE slab per block is written, so the
 // slab traffic is G x tiles x 9216 floats (4x less than one slab per 64x64 tile and block); a second
 // kernel sums the slabs in a fixed order (deterministic, no atomics).
+//
+// LDS images: S tile [32][PX+4] and B patch [32][PR rows][BWt+8] (4 zero floats of halo on either side of every row,
+// so that image rows start 16-byte aligned): both are filled with float4 global loads / ds_write_b128 and have
+// their column index XOR-swizzled by (channel>>3)&3, which makes the per-lane (lane = channel) MFMA operand reads
+// conflict-free although the row strides are multiples of 4 floats.
+//
+// The S width is a template parameter: on gfx950 the fp32 MFMA shares the vector ALU's issue (measured,
+// tools/mfma_valu.hip: every VALU instruction between MFMAs costs ~4.5 cycles of MFMA time, nothing overlaps), so
+// the MFMA loop must not compute addresses.  With the geometry known at compile time every operand read is
+// <one of 6 per-lane base registers> + immediate offset, the loop is fully unrolled (no register rotation moves),
+// and its only instructions are ds_read_b32 and v_mfma.
 #pragma once
 #include "gmk_common.h"
 
@@ -21,22 +32,52 @@ struct WgradGeom {
   long long total_chunks;
   int G;               // pixel-chunk groups (gridDim.x)
   int csT, cbT;        // 32-channel tiles
-  int PR, PC, PSb, npos;
   int bias_mode;       // 0 none, 1 dY = small tensor, 2 dY = big tensor
 };
 
 #define GMK_WG_T 32  // channel tile (both sides)
 
-template <int KS, int SB, int NT /* taps per block: KS*KS or KS (one ky row) */, int PX /* pixels per chunk */,
-          int NSLOT /* patch positions per thread */>
+// ---- compile-time geometry of a chunk (shared by the kernel, the launcher and the workspace planner) ----
+struct WgradPatch { int PX, PR, PC, PSb, npos, nslot; size_t lds; };
+constexpr WgradPatch gmk_wgrad_patch_for(int p, int SW, int ksize, int sb) {
+  WgradPatch w{};
+  const int rows = p / SW, BWt = SW * sb;
+  w.PX = p;
+  w.PR = sb == 1 ? rows + ksize - 1 : 2 * rows + ksize - 2;
+  w.PC = BWt + 8;
+  w.PSb = ((w.PR * w.PC + 31) / 32) * 32 + 4;  // == 4 (mod 32), room for a trash quad behind the patch
+  w.npos = w.PR * (BWt / 4);
+  w.nslot = (GMK_WG_T * w.npos + 255) / 256;
+  w.lds = sizeof(float) * ((size_t)GMK_WG_T * (p + 4) + (size_t)GMK_WG_T * w.PSb);
+  return w;
+}
+// pixels per chunk: whole rows, as many as fit the register / LDS budget (256 for stride 1, 128 for stride 2: the
+// stride-2 patch is ~4x the chunk); images are taken to be at least one chunk large (SH*SW >= PX, checked by the host)
+#define GMK_WG_MAXSLOT 24
+constexpr WgradPatch gmk_wgrad_patch(int SW, int ksize, int sb) {
+  int p = sb == 1 ? 256 : 128;
+  if (p > SW * SW) p = SW * SW;
+  while (p > SW) {
+    const WgradPatch w = gmk_wgrad_patch_for(p, SW, ksize, sb);
+    if (w.nslot <= GMK_WG_MAXSLOT && w.lds <= 150 * 1024) break;
+    p >>= 1;
+  }
+  if (p < SW) p = SW;
+  return gmk_wgrad_patch_for(p, SW, ksize, sb);
+}
+
+template <int KS, int SB, int NT /* taps per block: KS*KS or KS (one ky row) */, int LGSW /* log2 of the S width */>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
   constexpr int KK = KS * KS, PAD = (KS - 1) / 2, NTG = KK / NT, T = GMK_WG_T;
+  constexpr int SW = 1 << LGSW, BWt = SW * SB, QPR = BWt / 4;
+  constexpr WgradPatch GEO = gmk_wgrad_patch(SW, KS, SB);
+  constexpr int PX = GEO.PX, PR = GEO.PR, PC = GEO.PC, PSb = GEO.PSb, NPOS = GEO.npos, NSLOT = GEO.nslot;
   constexpr int SS = PX + 4;               // S tile row stride: 16-byte rows, columns XOR-swizzled by (row>>3)&3
   constexpr int NS = (T * PX / 4) / 256;   // float4 loads of the S tile per thread and chunk
   constexpr int WPX = PX / 4;              // pixels per wave and chunk
-  static_assert(NS >= 1 && WPX >= 2, "chunk too small");
+  static_assert(NS >= 1 && WPX >= 4 && (WPX % 4) == 0, "chunk too small");
+  static_assert(WPX % SW == 0 || SW % WPX == 0, "a wave's pixels are whole rows or a part of one row");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int PSb = g.PSb, PC = g.PC;
   float* Sl = smem;           // [32][SS]
   float* Bl = smem + T * SS;  // [32][PSb]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -45,7 +86,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
   const int tg = blockIdx.y % NTG;
   const int tile = blockIdx.y / NTG;
   const int cs0 = (tile / g.cbT) * T, cb0 = (tile % g.cbT) * T;
-  const int SHW = 1 << g.lgSHW, BHW = g.BHt * g.BWt;
+  const int SHW = 1 << g.lgSHW, BHW = g.BHt * BWt;
   const int cmax_s = (g.Cs - cs0) < T ? (g.Cs - cs0) : T, cmax_b = (g.Cb - cb0) < T ? (g.Cb - cb0) : T;
 
   f32x16 acc[NT];
@@ -59,36 +100,55 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
   const bool bias1 = g.bias_mode == 1 && tg == 0 && (tile % g.cbT) == 0;  // only the blocks the reduce kernel reads
   const bool bias2 = g.bias_mode == 2 && tg == 0 && (tile / g.cbT) == 0;
 
-  // S tile: float4 e = tid + u*256 -> (channel, pixel quad); B patch: NSLOT positions per thread, 32 channels each
-  int prow[NSLOT], pcol[NSLOT], pos_l[NSLOT];
-  bool has_pos[NSLOT];
+  // B patch: quad e = tid + k*256 -> (channel, patch row, quad of the image row); per slot: global offset, LDS
+  // offset, and (row | swizzle<<8), 0x3FF for a dead slot
+  int q_goff[NSLOT], q_loff[NSLOT], q_meta[NSLOT];
 #pragma unroll
   for (int k = 0; k < NSLOT; ++k) {
     const int e = tid + k * 256;
-    prow[k] = e / PC; pcol[k] = e % PC;
-    has_pos[k] = e < g.npos;
-    pos_l[k] = has_pos[k] ? e : g.npos;  // masked slots write a trash column
+    const int c = e / NPOS, r = e % NPOS;
+    const int prow = r / QPR, q = r % QPR;
+    const bool live = c < cmax_b;  // also false for e >= 32 * NPOS
+    q_goff[k] = live ? c * BHW + (prow - PAD) * BWt + 4 * q : 0;
+    q_loff[k] = live ? c * PSb + prow * PC + 4 + 4 * q : PR * PC;  // dead slots write the trash quad of channel 0
+    q_meta[k] = live ? (prow | (((c >> 3) & 3) << 8)) : 0x3FF;
   }
-  const int asw = (jj >> 3) & 3;
-  const int bbase = jj * PSb;
-  int tapoff[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int ky = (NT == KK) ? t / KS : tg, kx = (NT == KK) ? t % KS : t;
-    tapoff[t] = ky * PC + kx;
+  // zero the halo quads of every patch row once (image rows are written at columns 4 .. 4+BWt-1 only)
+  for (int e = tid; e < 2 * T * PR; e += 256) {
+    const int side = e & 1, rr = e >> 1;
+    const int c = rr / PR, prow = rr % PR;
+    *(float4*)(Bl + c * PSb + prow * PC + (side ? 4 + BWt : 0)) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
+  // ---- per-lane operand bases of the MFMA loop (everything else is an immediate) ----
+  // This wave reduces pixels wp0 .. wp0+WPX-1 of the chunk; k-step s takes pixels wp0 + 2s + h.
+  const int asw = (jj >> 3) & 3;
+  const int wp0 = wave * WPX;
+  // A: logical column wp0 + 2s + h of S row jj, stored at column ^ asw.  (2s + h) & 3 = (2s & 2) + h:
+  const float* abase[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) abase[m] = Sl + jj * SS + wp0 + (((2 * m) + h) ^ asw);  // + (2s & ~3)
+  // B: logical index lc + K(s,t), K compile time, lc = wave / lane part; stored at index ^ asw:
+  //    (lc + 4a + m) ^ asw = ((lc + m) ^ asw) + 4a
+  const int lc = (((wp0 >> LGSW) * SB) * PC) + ((wp0 & (SW - 1)) + h) * SB + ((NT == KK) ? 0 : tg * PC);  // tap-row blocks (5x5): ky = tg
+  const float* bbase[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) bbase[m] = Bl + jj * PSb + ((lc + m) ^ asw);  // + (K & ~3) for K & 3 == m
+
   float4 sr[NS];
-  float br[NSLOT][T];
+  float4 br[NSLOT];
   // branch-free batched loads of one pixel chunk into registers (a chunk index past the end re-reads the
-  // last chunk; its contribution is skipped).  Patch positions outside the image read offset GMK_OOB -> 0.
+  // last chunk; its contribution is skipped).  Patch rows outside the image re-read a valid quad, zeroed on the way
+  // to LDS.
   const long long last_chunk = g.total_chunks - 1;
+  int cur_r0 = 0;  // first S row of the chunk currently held in the prefetch registers
   auto load_chunk = [&](long long ch) {
     ch = ch < last_chunk ? ch : last_chunk;
     const long long pix = ch * PX;
     const long long n = pix >> g.lgSHW;
     const int pin = (int)(pix & (SHW - 1));
-    const int r0 = pin >> g.lgSW;
+    const int r0 = pin >> LGSW;
+    cur_r0 = r0;
     const float* sbase = g.s + ((n * g.Cs + cs0) << g.lgSHW) + pin;
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
@@ -97,14 +157,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
       const int cc = c < cmax_s ? c : cmax_s - 1;  // ragged tile: re-read a valid channel, zeroed on the way to LDS
       sr[u] = *(const float4*)(sbase + ((size_t)cc << g.lgSHW) + p4 * 4);
     }
-    const __amdgpu_buffer_rsrc_t rb = gmk_make_rsrc(g.b + (n * g.Cb + cb0) * (long long)BHW, (long long)cmax_b * BHW * 4);
+    const float* bbase_g = g.b + (n * g.Cb + cb0) * (long long)BHW + (long long)(r0 * SB) * BWt;
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k) {
-      const int iy = r0 * SB + prow[k] - PAD, ix = pcol[k] - PAD;
-      const bool okp = has_pos[k] & (iy >= 0) & (iy < g.BHt) & (ix >= 0) & (ix < g.BWt);
-      const int voff = okp ? (iy * g.BWt + ix) * 4 : GMK_OOB;
-#pragma unroll
-      for (int c = 0; c < T; ++c) br[k][c] = gmk_buffer_load(rb, voff, c * BHW * 4);  // c >= cmax_b: outside the descriptor -> 0
+      const int iy = r0 * SB + (q_meta[k] & 0xFF) - PAD;
+      const bool ok = (q_meta[k] != 0x3FF) & (iy >= 0) & (iy < g.BHt);
+      br[k] = *(const float4*)(bbase_g + (ok ? q_goff[k] : 0));
     }
   };
   auto store_chunk = [&]() {
@@ -121,9 +179,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
       *(float4*)(Sl + c * SS + p4 * 4) = w2;
     }
 #pragma unroll
-    for (int k = 0; k < NSLOT; ++k)
-#pragma unroll
-      for (int c = 0; c < T; ++c) Bl[c * PSb + pos_l[k]] = br[k][c];
+    for (int k = 0; k < NSLOT; ++k) {
+      const int iy = cur_r0 * SB + (q_meta[k] & 0xFF) - PAD;
+      const bool ok = (q_meta[k] != 0x3FF) & (iy >= 0) & (iy < g.BHt);
+      const int sw = (q_meta[k] >> 8) & 3;
+      float4 v = ok ? br[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 w1 = (sw & 1) ? make_float4(v.y, v.x, v.w, v.z) : v;
+      const float4 w2 = (sw & 2) ? make_float4(w1.z, w1.w, w1.x, w1.y) : w1;
+      *(float4*)(Bl + q_loff[k]) = w2;
+    }
   };
 
   long long ch = blockIdx.x;
@@ -145,34 +209,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
 #pragma unroll
       for (int k = 0; k < PX / 8; ++k) bsum += v[k];
     } else if (bias2) {
-      const int cnt = ((PX >> g.lgSW) * SB) << g.lgBWt;  // interior pixels of the patch, split 8 ways
+      constexpr int cnt = ((PX >> LGSW) * SB) * BWt;  // interior pixels of the patch, split 8 ways
       for (int q = bpart; q < cnt; q += 8) {
-        const int r = q >> g.lgBWt, x = q & (g.BWt - 1);
-        bsum += Bl[bch * PSb + (r + PAD) * PC + x + PAD];
+        const int r = q / BWt, x = q % BWt;
+        bsum += Bl[bch * PSb + (((r + PAD) * PC + 4 + x) ^ ((bch >> 3) & 3))];
       }
     }
-    // MFMA over this wave's pixels, software-pipelined by hand: the operands of k-step s+1 are read from LDS
-    // into a second register set before the NT MFMAs of step s issue (with one wave per SIMD nothing else
-    // hides the LDS latency; left alone the compiler reuses two registers and waits before every MFMA).
-    {
-      float av_n, bv_n[NT];
-      auto read_step = [&](int s2) {
-        const int p = wave * WPX + 2 * s2 + h;
-        av_n = Sl[jj * SS + (p ^ asw)];
-        const int poff = bbase + ((p >> g.lgSW) * SB) * PC + (p & (g.SW - 1)) * SB;
+    // MFMA over this wave's pixels: fully unrolled, every operand address = per-lane base + immediate
 #pragma unroll
-        for (int t = 0; t < NT; ++t) bv_n[t] = Bl[poff + tapoff[t]];
-      };
-      read_step(0);
-#pragma unroll 2
-      for (int s2 = 0; s2 < WPX / 2; ++s2) {
-        const float av = av_n;
-        float bv[NT];
+    for (int s2 = 0; s2 < WPX / 2; ++s2) {
+      const float av = abase[s2 & 1][(2 * s2) & ~3];
+      // local pixel 2*s2 of the wave -> (row, column) relative to the wave's first pixel
+      const int lr = (WPX >= SW) ? (2 * s2) >> LGSW : 0;
+      const int lcx = (WPX >= SW) ? (2 * s2) & (SW - 1) : 2 * s2;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) bv[t] = bv_n[t];
-        if (s2 + 1 < WPX / 2) read_step(s2 + 1);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) {
+        const int ky = (NT == KK) ? t / KS : 0, kx = (NT == KK) ? t % KS : t;
+        const int K = (lr * SB + ky) * PC + lcx * SB + kx + 4 - PAD;  // a compile-time constant after unrolling
+        const float bv = bbase[K & 3][K & ~3];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
       }
     }
   }
@@ -247,20 +302,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
 int gmk_launch_wgrad_k3(WgradGeom& g, int sb, float* dw, float* dbias, hipStream_t s);
 int gmk_launch_wgrad_k5(WgradGeom& g, int sb, float* dw, float* dbias, hipStream_t s);
 
-// pixels per chunk: whole rows of one image, 128 (stride 1) / 64 (stride 2: the patch is ~4x the chunk)
-static inline int gmk_wgrad_patch_positions(int p, int SW, int ksize, int sb) {
-  const int rows = p / SW;
-  return sb == 1 ? (rows + ksize - 1) * (SW + ksize - 1) : (2 * rows + ksize - 2) * (2 * SW + ksize - 2);
-}
-// pixels per chunk: whole rows of one image, as many as keep the patch within 3 positions per thread
-// (256 for stride 1, 128 for stride 2: the stride-2 patch is ~4x the chunk)
-#define GMK_WG_MAXSLOT 3
-static inline int gmk_wgrad_chunk_px(int SH, int SW, int ksize, int sb) {
-  int p = sb == 1 ? 256 : 128;
-  if (p > SH * SW) p = SH * SW;
-  while (p > SW && gmk_wgrad_patch_positions(p, SW, ksize, sb) > GMK_WG_MAXSLOT * 256 - 1) p >>= 1;
-  if (p < SW) p = SW;
-  return p;
+static inline bool gmk_wgrad_supported(int SH, int SW, int ksize, int sb) {
+  if (!gmk_is_pow2(SH) || !gmk_is_pow2(SW) || SW < 8 || SW * sb > 128 || (SW * sb) % 4 != 0) return false;
+  const WgradPatch w = gmk_wgrad_patch(SW, ksize, sb);
+  return (long long)SH * SW >= w.PX && w.PX >= 32 && w.nslot <= GMK_WG_MAXSLOT && w.lds <= 160 * 1024;
 }
 static inline size_t gmk_wgrad_slab_floats(int ksize) {
   const int KK = ksize * ksize, NT = ksize == 3 ? KK : ksize;
@@ -270,42 +315,38 @@ static inline size_t gmk_wgrad_slab_floats(int ksize) {
 template <int KS>
 static int gmk_launch_wgrad_impl(WgradGeom& g, int sb, float* dw, float* dbias, hipStream_t s) {
   constexpr int KK = KS * KS, NT = (KS == 3) ? KK : KS, NTG = KK / NT, T = GMK_WG_T;
-  const int rows = g.P / g.SW;
-  if (sb == 1) { g.PR = rows + KS - 1; g.PC = g.SW + KS - 1; }
-  else { g.PR = 2 * rows + KS - 2; g.PC = 2 * g.SW + KS - 2; }
-  g.npos = g.PR * g.PC;
-  if (g.npos > GMK_WG_MAXSLOT * 256 - 1) return GMK_E_SHAPE;  // <= 3 patch positions per thread (+ a trash column)
-  const int nslot = (g.npos + 1 + 255) / 256;
-  g.PSb = (g.npos + 1) | 1;
-  size_t lds = sizeof(float) * (T * (size_t)(g.P + 4) + T * (size_t)g.PSb);
+  if (!gmk_wgrad_supported(g.SH, g.SW, KS, sb)) return GMK_E_SHAPE;
+  const WgradPatch w = gmk_wgrad_patch(g.SW, KS, sb);
+  if (w.PX != g.P) return GMK_E_SHAPE;
+  size_t lds = w.lds;
   const size_t red = sizeof(float) * 2 * NT * T * T;
   if (lds < red) lds = red;
-  if (lds > 160 * 1024) return GMK_E_SHAPE;
   dim3 grid(g.G, g.csT * g.cbT * NTG);
-#define GMK_WG_LAUNCH(SB_, PX_, NSLOT_)                                                                            \
+#define GMK_WG_LAUNCH(SB_, LGSW_)                                                                                  \
   do {                                                                                                             \
-    auto kern = conv_wgrad_kernel<KS, SB_, NT, PX_, NSLOT_>;                                                       \
+    auto kern = conv_wgrad_kernel<KS, SB_, NT, LGSW_>;                                                             \
     if (lds > 64 * 1024) {                                                                                         \
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return (int)e;                                                                          \
     }                                                                                                              \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, g);                                                          \
   } while (0)
-#define GMK_WG_SLOTS(SB_, PX_)                                                     \
-  do {                                                                             \
-    if (nslot == 1) GMK_WG_LAUNCH(SB_, PX_, 1);                                    \
-    else if (nslot == 2) GMK_WG_LAUNCH(SB_, PX_, 2);                               \
-    else GMK_WG_LAUNCH(SB_, PX_, 3);                                               \
-  } while (0)
   if (sb == 1) {
-    if (g.P == 256) GMK_WG_SLOTS(1, 256); else if (g.P == 128) GMK_WG_SLOTS(1, 128); else if (g.P == 64) GMK_WG_SLOTS(1, 64);
-    else if (g.P == 32) GMK_WG_SLOTS(1, 32);
-    else return GMK_E_SHAPE;
+    switch (g.lgSW) {
+      case 3: GMK_WG_LAUNCH(1, 3); break;
+      case 4: GMK_WG_LAUNCH(1, 4); break;
+      case 5: GMK_WG_LAUNCH(1, 5); break;
+      case 6: GMK_WG_LAUNCH(1, 6); break;
+      default: return GMK_E_SHAPE;
+    }
   } else {
-    if (g.P == 128) GMK_WG_SLOTS(2, 128); else if (g.P == 64) GMK_WG_SLOTS(2, 64); else if (g.P == 32) GMK_WG_SLOTS(2, 32);
-    else return GMK_E_SHAPE;
+    switch (g.lgSW) {
+      case 3: GMK_WG_LAUNCH(2, 3); break;
+      case 4: GMK_WG_LAUNCH(2, 4); break;
+      case 5: GMK_WG_LAUNCH(2, 5); break;
+      default: return GMK_E_SHAPE;
+    }
   }
-#undef GMK_WG_SLOTS
 #undef GMK_WG_LAUNCH
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;

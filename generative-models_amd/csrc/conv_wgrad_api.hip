@@ -5,7 +5,7 @@
 static void wgrad_plan(WgradGeom& g, int N, int Cs, int Cb, int SH, int SW, int ksize, int sb) {
   g.N = N; g.Cs = Cs; g.Cb = Cb; g.SH = SH; g.SW = SW; g.BHt = SH * sb; g.BWt = SW * sb;
   g.lgSW = gmk_ilog2(SW); g.lgSHW = gmk_ilog2((int64_t)SH * SW); g.lgBWt = gmk_ilog2(g.BWt);
-  g.P = gmk_wgrad_chunk_px(SH, SW, ksize, sb); g.lgP = gmk_ilog2(g.P);
+  g.P = gmk_wgrad_patch(SW, ksize, sb).PX; g.lgP = gmk_ilog2(g.P);
   g.total_chunks = ((long long)N * SH * SW) / g.P;
   g.csT = (Cs + GMK_WG_T - 1) / GMK_WG_T; g.cbT = (Cb + GMK_WG_T - 1) / GMK_WG_T;
   const int ntg = ksize == 3 ? 1 : ksize;
@@ -45,8 +45,8 @@ extern "C" size_t gmk_deconv2d_wgrad_workspace_bytes(int N, int Cin, int H, int 
 static int wgrad_run(const float* small, const float* big, float* dw, float* dbias, int bias_mode, int N, int Cs,
                      int Cb, int SH, int SW, int ksize, int sb, void* ws, size_t ws_bytes, hipStream_t s) {
   if (ksize != 3 && ksize != 5) return GMK_E_UNSUPPORTED;
-  if (!gmk_is_pow2(SH) || !gmk_is_pow2(SW) || SW * sb > 128 || SH * SW < 32) return GMK_E_SHAPE;
-  if (!gmk_aligned16(ws)) return GMK_E_ALIGN;
+  if (!gmk_wgrad_supported(SH, SW, ksize, sb)) return GMK_E_SHAPE;  // square-ish power-of-two images, 8 <= width <= 64
+  if (!gmk_aligned16(ws) || !gmk_aligned16(small) || !gmk_aligned16(big)) return GMK_E_ALIGN;
   WgradGeom g{};
   wgrad_plan(g, N, Cs, Cb, SH, SW, ksize, sb);
   if (ws_bytes < slab_bytes(g, ksize)) return GMK_E_WORKSPACE;
