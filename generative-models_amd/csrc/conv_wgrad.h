@@ -235,25 +235,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
   // ---- combine the four waves' partial tiles in LDS (fixed order), one slab per block ----
   // slab[(blockIdx.x * gridDim.y + blockIdx.y)][t][cs 32][cb 32] followed by 32 bias partials
   constexpr int TILE = NT * T * T, SLAB = TILE + T;
-  float* R = smem;  // [2][TILE]
-#pragma unroll 1
-  for (int ph = 0; ph < 2; ++ph) {
-    __syncthreads();
-    if ((wave >> 1) == ph) {
-      float* Rw = R + (wave & 1) * TILE;
+  float* R = smem;  // [4][TILE]: every wave parks its partial tile, then all threads sum the four in a fixed order
+  __syncthreads();
+  {
+    float* Rw = R + wave * TILE;
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int cs = (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int idx = (t * T + cs) * T + jj;
-          Rw[idx] = (ph == 0) ? acc[t][r] : Rw[idx] + acc[t][r];
-        }
-    }
+      for (int r = 0; r < 16; ++r) {
+        const int cs = (r & 3) + 8 * (r >> 2) + 4 * h;
+        Rw[(t * T + cs) * T + jj] = acc[t][r];
+      }
   }
   __syncthreads();
   float* out = g.slab + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (size_t)SLAB;
-  for (int e = tid; e < TILE; e += 256) out[e] = R[e] + R[TILE + e];
+  for (int e = tid * 4; e < TILE; e += 1024) {
+    const float4 r0 = *(const float4*)(R + e), r1 = *(const float4*)(R + TILE + e);
+    const float4 r2 = *(const float4*)(R + 2 * TILE + e), r3 = *(const float4*)(R + 3 * TILE + e);
+    *(float4*)(out + e) = make_float4((r0.x + r1.x) + (r2.x + r3.x), (r0.y + r1.y) + (r2.y + r3.y),
+                                      (r0.z + r1.z) + (r2.z + r3.z), (r0.w + r1.w) + (r2.w + r3.w));
+  }
   __syncthreads();
   // bias partials: 8 parts per channel, summed in a fixed order
   R[bpart * T + bch] = bsum;
@@ -319,7 +320,7 @@ static int gmk_launch_wgrad_impl(WgradGeom& g, int sb, float* dw, float* dbias, 
   const WgradPatch w = gmk_wgrad_patch(g.SW, KS, sb);
   if (w.PX != g.P) return GMK_E_SHAPE;
   size_t lds = w.lds;
-  const size_t red = sizeof(float) * 2 * NT * T * T;
+  const size_t red = sizeof(float) * 4 * NT * T * T;  // four parked partial tiles
   if (lds < red) lds = red;
   dim3 grid(g.G, g.csT * g.cbT * NTG);
 #define GMK_WG_LAUNCH(SB_, LGSW_)                                                                                  \
