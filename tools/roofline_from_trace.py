@@ -1,0 +1,15 @@
+"""From a rocprofv3 kernel trace of `bench.py`, isolate the launches of bench.py's roofline leg (the dominant conv kernel
+timed alone after the train steps, i.e. every launch of it after the last adamw_kernel) and print their average duration,
+to be compared with `roofline.launch_us` of the same run.   python tools/roofline_from_trace.py b_kernel_trace.csv"""
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+last = max(i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("adamw_kernel"))
+leg = [r for r in rows[last + 1:] if r["Kernel_Name"].startswith("void conv_igemm_kernel<0, 3, 8, 1, 2, 1>")]
+d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in leg]
+timed = d[5:]  # the first 5 are the leg's warm-up launches
+print("kernel,launches_in_roofline_leg,timed_launches,avg_us_timed,min_us,max_us")
+print(f'"conv_igemm_kernel<0, 3, 8, 1, 2, 1> (64->64 3x3 s1, 16x16, B=256, gelu + act\')",{len(d)},{len(timed)},'
+      f"{sum(timed) / len(timed) / 1e3:.2f},{min(timed) / 1e3:.2f},{max(timed) / 1e3:.2f}")
