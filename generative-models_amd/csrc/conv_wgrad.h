@@ -51,11 +51,23 @@ constexpr WgradPatch gmk_wgrad_patch_for(int p, int SW, int ksize, int sb) {
   w.lds = sizeof(float) * ((size_t)GMK_WG_T * (p + 4) + (size_t)GMK_WG_T * w.PSb);
   return w;
 }
-// pixels per chunk: whole rows, as many as fit the register / LDS budget (256 for stride 1, 128 for stride 2: the
-// stride-2 patch is ~4x the chunk); images are taken to be at least one chunk large (SH*SW >= PX, checked by the host)
+// pixels per chunk: whole rows, 128 for stride 1 and 64 for stride 2 (the stride-2 patch is ~4x the chunk).  Larger
+// chunks (256 / 128) and a one-barrier reduction over 4 parked tiles make this kernel ~8 % faster ALONE, but at ~150 KB
+// of LDS it then owns its CU; at <= 74 KB the dgrad kernels of the main stream co-reside with it and the whole
+// backward pass is 2 % faster (measured A/B on one device: 1.347 -> 1.323 ms/step).  Images are taken to be at least
+// one chunk large (SH*SW >= PX, checked by the host).
 #define GMK_WG_MAXSLOT 24
+#ifndef GMK_WG_MAXPX_S1
+#define GMK_WG_MAXPX_S1 128
+#endif
+#ifndef GMK_WG_MAXPX_S2
+#define GMK_WG_MAXPX_S2 64
+#endif
+#ifndef GMK_WG_RED_REGIONS
+#define GMK_WG_RED_REGIONS 2  /* partial tiles parked in LDS at once by the in-block reduction (4, 2 or 1) */
+#endif
 constexpr WgradPatch gmk_wgrad_patch(int SW, int ksize, int sb) {
-  int p = sb == 1 ? 256 : 128;
+  int p = sb == 1 ? GMK_WG_MAXPX_S1 : GMK_WG_MAXPX_S2;
   if (p > SW * SW) p = SW * SW;
   while (p > SW) {
     const WgradPatch w = gmk_wgrad_patch_for(p, SW, ksize, sb);
@@ -235,25 +247,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
   // ---- combine the four waves' partial tiles in LDS (fixed order), one slab per block ----
   // slab[(blockIdx.x * gridDim.y + blockIdx.y)][t][cs 32][cb 32] followed by 32 bias partials
   constexpr int TILE = NT * T * T, SLAB = TILE + T;
-  float* R = smem;  // [4][TILE]: every wave parks its partial tile, then all threads sum the four in a fixed order
-  __syncthreads();
-  {
-    float* Rw = R + wave * TILE;
+  // The four waves' partial tiles are summed in the fixed order (w0 + w1) + (w2 + w3) ... through RR regions of LDS:
+  // RR = 4: every wave parks its tile, one barrier; RR = 2 / 1: in rounds (less LDS, so that blocks of other kernels
+  // can share the CU).
+  constexpr int RR = GMK_WG_RED_REGIONS;
+  float* R = smem;  // [RR][TILE]
+#pragma unroll 1
+  for (int ph = 0; ph < 4 / RR; ++ph) {
+    __syncthreads();
+    if (wave / RR == ph) {
+      float* Rw = R + (wave % RR) * TILE;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int cs = (r & 3) + 8 * (r >> 2) + 4 * h;
-        Rw[(t * T + cs) * T + jj] = acc[t][r];
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int cs = (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int idx = (t * T + cs) * T + jj;
+          Rw[idx] = (ph == 0) ? acc[t][r] : Rw[idx] + acc[t][r];
+        }
+    }
   }
   __syncthreads();
   float* out = g.slab + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (size_t)SLAB;
   for (int e = tid * 4; e < TILE; e += 1024) {
-    const float4 r0 = *(const float4*)(R + e), r1 = *(const float4*)(R + TILE + e);
-    const float4 r2 = *(const float4*)(R + 2 * TILE + e), r3 = *(const float4*)(R + 3 * TILE + e);
-    *(float4*)(out + e) = make_float4((r0.x + r1.x) + (r2.x + r3.x), (r0.y + r1.y) + (r2.y + r3.y),
-                                      (r0.z + r1.z) + (r2.z + r3.z), (r0.w + r1.w) + (r2.w + r3.w));
+    float4 r0 = *(const float4*)(R + e);
+    if (RR >= 2) {
+      const float4 r1 = *(const float4*)(R + TILE + e);
+      r0 = make_float4(r0.x + r1.x, r0.y + r1.y, r0.z + r1.z, r0.w + r1.w);
+    }
+    if (RR == 4) {
+      const float4 r2 = *(const float4*)(R + 2 * TILE + e), r3 = *(const float4*)(R + 3 * TILE + e);
+      r0 = make_float4(r0.x + (r2.x + r3.x), r0.y + (r2.y + r3.y), r0.z + (r2.z + r3.z), r0.w + (r2.w + r3.w));
+    }
+    *(float4*)(out + e) = r0;
   }
   __syncthreads();
   // bias partials: 8 parts per channel, summed in a fixed order
@@ -320,7 +346,7 @@ static int gmk_launch_wgrad_impl(WgradGeom& g, int sb, float* dw, float* dbias, 
   const WgradPatch w = gmk_wgrad_patch(g.SW, KS, sb);
   if (w.PX != g.P) return GMK_E_SHAPE;
   size_t lds = w.lds;
-  const size_t red = sizeof(float) * 4 * NT * T * T;  // four parked partial tiles
+  const size_t red = sizeof(float) * GMK_WG_RED_REGIONS * NT * T * T;  // parked partial tiles
   if (lds < red) lds = red;
   dim3 grid(g.G, g.csT * g.cbT * NTG);
 #define GMK_WG_LAUNCH(SB_, LGSW_)                                                                                  \
