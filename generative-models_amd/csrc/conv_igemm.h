@@ -205,7 +205,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
     for (int py = 0; py < ((MODE == 2) ? 2 : 1); ++py) {
-      __syncthreads();  // main-loop LDS reads / the previous pass's reads are done
+      // bias of this lane's channels and, for dgrad, the act' factors of its rows: ALL fetched before the math, so the
+      // HBM latency of the act' read is paid once per pass and not once per store instruction
+      float bvs[32 / CPI];
+      long long idxs[32 / CPI];
+      float4 dds[32 / CPI];
+#pragma unroll
+      for (int it = 0; it < 32 / CPI; ++it) {
+        const int m = m0 + (wm * MT + i) * 32 + ec + it * CPI;
+        const int mc = m < g.M ? m : g.M - 1;  // clamped for the prefetch; rows beyond M are not stored
+        bvs[it] = (g.epi == 0 && g.bias) ? g.bias[mc] : 0.f;
+        if (MODE != 2) idxs[it] = (nq * g.M + mc) * (long long)BHW + remq;
+        else idxs[it] = (nq * g.M + mc) * (long long)(4 * BHW) + (long long)(2 * byq + py) * (2 * g.BW) + 2 * bxq;
+        dds[it] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (g.epi != 0 && g.dact_in && pok) dds[it] = *(const float4*)(g.dact_in + idxs[it]);
+      }
+      gmk_lds_barrier();  // main-loop LDS reads / the previous pass's reads are done (the prefetches above stay in flight)
 #pragma unroll
       for (int k4 = 0; k4 < 4; ++k4) {
         if (MODE != 2) {
@@ -219,14 +234,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
                                           acc[py * 2][i][4 * k4 + 3], acc[py * 2 + 1][i][4 * k4 + 3]);
         }
       }
-      __syncthreads();
-      // bias of this lane's channels, fetched before the math (one L1-resident load per store instruction)
-      float bvs[32 / CPI];
-#pragma unroll
-      for (int it = 0; it < 32 / CPI; ++it) {
-        const int m = m0 + (wm * MT + i) * 32 + ec + it * CPI;
-        bvs[it] = (g.epi == 0 && g.bias && m < g.M) ? g.bias[m] : 0.f;
-      }
+      gmk_lds_barrier();
       // the activation switch is hoisted out of the store loop: GELU (the reference default) and identity
       // get straight-line code, the other activations share the generic switch
       auto store_rows = [&](auto actf) {
@@ -236,9 +244,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
           const int m = m0 + (wm * MT + i) * 32 + c;
           if (m >= g.M || !pok) continue;
           float4 v = *(const float4*)(Ew + c * ES + 4 * eq);
-          long long idx;
-          if (MODE != 2) idx = (nq * g.M + m) * (long long)BHW + remq;
-          else idx = (nq * g.M + m) * (long long)(4 * BHW) + (long long)(2 * byq + py) * (2 * g.BW) + 2 * bxq;
+          const long long idx = idxs[it];
           if (g.epi == 0) {
             const float bv = bvs[it];
             float4 a, d;
@@ -249,10 +255,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
             *(float4*)(g.y + idx) = a;
             if (g.dact_out) *(float4*)(g.dact_out + idx) = d;
           } else {
-            if (g.dact_in) {
-              const float4 dd = *(const float4*)(g.dact_in + idx);
-              v.x *= dd.x; v.y *= dd.y; v.z *= dd.z; v.w *= dd.w;
-            }
+            const float4 dd = dds[it];
+            v.x *= dd.x; v.y *= dd.y; v.z *= dd.z; v.w *= dd.w;
             *(float4*)(g.y + idx) = v;
           }
         }
