@@ -185,12 +185,36 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const GemmArgs g) {
   }
   const int j = j0 + wc * 32 + l31;
   if (j >= g.N) return;
+  if (g.slab) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (i < g.M) g.slab[((size_t)blockIdx.z * g.M + i) * g.N + j] = acc[r];
+    }
+    return;
+  }
+  // direct epilogue: the per-element factors (act' of dgrad) are all fetched before the math, the bias once per lane
+  float mulv[16];
+  const float bv = (g.epi == GEPI_BIAS_ACT && g.bias) ? g.bias[j] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    const int ic = i < g.M ? i : g.M - 1;
+    mulv[r] = (g.epi == GEPI_MUL && g.mul) ? g.mul[(size_t)ic * g.ldc + j] : 1.f;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int i = i0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
     if (i >= g.M) continue;
-    if (g.slab) g.slab[((size_t)blockIdx.z * g.M + i) * g.N + j] = acc[r];
-    else gemm_epilogue(g, i, j, acc[r]);
+    const size_t idx = (size_t)i * g.ldc + j;
+    if (g.epi == GEPI_BIAS_ACT) {
+      float a, d;
+      gmk_act_fwd(g.act, acc[r] + bv, a, d);
+      g.C[idx] = a;
+      if (g.dact) g.dact[idx] = d;
+    } else {
+      g.C[idx] = acc[r] * mulv[r];
+    }
   }
 }
 
