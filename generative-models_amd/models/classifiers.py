@@ -100,36 +100,44 @@ class Classifier(nn.Module):
 
 
 def compute_accuracy(outputs, labels):
+    """Top-1 accuracy of a batch in percent (same value as reference classifiers.py:69-74)."""
     with torch.no_grad():
-        batch_size = labels.size(0)
-        pred = outputs.max(1)[1]
-        acc = pred.eq(labels).sum().item() * 100.0 / batch_size
-        return acc
+        hits = (outputs.argmax(dim=1) == labels).sum().item()
+    return 100.0 * hits / labels.size(0)
+
+
+def _epoch_accuracy(classifier, dataloader, device, step=None):
+    """Mean of the per-batch accuracies over one pass; `step(outputs, labels)` runs the optimisation when given."""
+    accs = []
+    for images, labels in dataloader:
+        images, labels = images.to(device), labels.to(device)
+        outputs = classifier(images)
+        if step is not None:
+            step(outputs, labels)
+        accs.append(compute_accuracy(outputs, labels))
+    return np.mean(accs)
 
 
 def train_classifier(args, classifier=None, train_dataloader=None, test_dataloader=None, device=None):
-    """/root/reference/models/classifiers.py:77-113: CE loss, AdamW, cosine LR per iteration; saves the full model."""
-    print(f'\n\nTraining CIFAR-10 Classifier\n\n')
-    if classifier is None:
-        classifier = Classifier(args=args).to(device)
+    """Auxiliary model training (reference classifiers.py:77-113): cross entropy, AdamW, cosine LR stepped every
+    iteration over epochs * len(loader) steps; the full model object is saved, as the metrics' loader expects."""
+    print('\n\nTraining CIFAR-10 Classifier\n\n')
+    classifier = Classifier(args=args).to(device) if classifier is None else classifier
     optim = torch.optim.AdamW(classifier.parameters(), lr=args.lr, weight_decay=args.wd)
-    loss_fn = nn.CrossEntropyLoss()
-    lr_scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer=optim, T_max=args.epochs * len(train_dataloader))
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer=optim, T_max=args.epochs * len(train_dataloader))
+    criterion = nn.CrossEntropyLoss()
+
+    def step(outputs, labels):
+        optim.zero_grad()
+        criterion(outputs, labels).backward()
+        optim.step()
+        sched.step()
+
     for epoch in range(args.epochs):
         classifier.train()
-        tr_accs = []
-        for images, labels in train_dataloader:
-            images, labels = images.to(device), labels.to(device)
-            outputs = classifier(images)
-            loss = loss_fn(outputs, labels)
-            optim.zero_grad()
-            loss.backward()
-            optim.step()
-            lr_scheduler.step()
-            tr_accs.append(compute_accuracy(outputs, labels))
-        train_acc = np.mean(tr_accs)
+        train_acc = _epoch_accuracy(classifier, train_dataloader, device, step=step)
         test_acc = evaluate_classifier(classifier, test_dataloader=test_dataloader, device=device)
-        print(f'Epoch {epoch}  train {train_acc:.2f}  test {test_acc:.2f}  LR {lr_scheduler.get_last_lr()[0]:.4f}')
+        print(f'Epoch {epoch}  train {train_acc:.2f}  test {test_acc:.2f}  LR {sched.get_last_lr()[0]:.4f}')
     checkpoint_path = f'checkpoints/cifar_classifier_{args.latent_size}.pth'
     print(f'\n\nSaving classifier model checkpoint to {checkpoint_path}')
     torch.save(classifier, checkpoint_path)
@@ -137,11 +145,7 @@ def train_classifier(args, classifier=None, train_dataloader=None, test_dataload
 
 
 def evaluate_classifier(classifier, test_dataloader=None, device=None):
-    te_accs = []
+    """Eval-mode pass (libgmk forward), reference classifiers.py:115-124."""
     classifier.eval()
     with torch.no_grad():
-        for images, labels in test_dataloader:
-            images, labels = images.to(device), labels.to(device)
-            outputs = classifier(images)
-            te_accs.append(compute_accuracy(outputs, labels))
-    return np.mean(te_accs)
+        return _epoch_accuracy(classifier, test_dataloader, device)
