@@ -58,30 +58,26 @@ def compute_test_loss(args, model, beta=None, test_dataloader=None, device=None)
     """main.py:73-111: eval-mode losses plus mean |mu| and mean sigma of the latent."""
     import torch.nn.functional as F
     model.eval()
+    n = len(test_dataloader)
+    acc = torch.zeros(4, device=device)   # rec, kl, mean |mu|, mean sigma
     with torch.no_grad():
-        total_test_rec_loss = 0
-        total_test_kl_loss = 0
-        latent_mean = 0
-        latent_std = 0
-        for test_image, label in test_dataloader:
+        for test_image, _ in test_dataloader:
             test_image = test_image.to(device)
-            test_reconstructed = model(test_image)
-            total_test_rec_loss += F.mse_loss(test_reconstructed, test_image)
-            if args.variational:
-                mu = model.stats[:, :, 0]
-                log_var = model.stats[:, :, 1]
-                sigma = torch.exp(0.5 * log_var)
-                if args.mse:
-                    test_kl_loss = (mu ** 2).sum(1).mean(0) + ((sigma - 1) ** 2).sum(1).mean(0)
-                else:
-                    test_kl_loss = torch.mean(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=0)
-                total_test_kl_loss += test_kl_loss
-                latent_mean += mu.abs().mean()
-                latent_std += sigma.abs().mean()
-        num_test_batches = len(test_dataloader)
-        avg_test_kl_loss = beta * total_test_kl_loss / num_test_batches
-        avg_test_rec_loss = total_test_rec_loss / num_test_batches
-        return latent_mean / num_test_batches, latent_std / num_test_batches, avg_test_rec_loss, avg_test_kl_loss
+            acc[0] += F.mse_loss(model(test_image), test_image)
+            if not args.variational:
+                continue
+            mu, log_var = model.stats[:, :, 0], model.stats[:, :, 1]
+            sigma = torch.exp(0.5 * log_var)
+            if args.mse:
+                acc[1] += (mu ** 2).sum(1).mean(0) + ((sigma - 1) ** 2).sum(1).mean(0)
+            else:
+                acc[1] += (-0.5 * (1 + log_var - mu ** 2 - log_var.exp()).sum(dim=1)).mean(dim=0)
+            acc[2] += mu.abs().mean()
+            acc[3] += sigma.abs().mean()
+    rec, kl, latent_mean, latent_std = (acc / n).unbind()
+    if not args.variational:
+        kl = latent_mean = latent_std = 0
+    return latent_mean, latent_std, rec, beta * kl
 
 
 def compute_metrics(autoencoder=None, classifier=None, real_images=None, samples=None, debug=False):
@@ -220,14 +216,9 @@ def main(args):
                 print(f'{time_str}  Epoch {epoch:>3d}   {loss_str}{latent_stats_str}{metrics_str}{changes_str}')
                 plot_grid(model, train_input_images[:4], name=experiment_str + '_train')
                 plot_grid(model, test_input_images[:4], name=experiment_str + '_test')
-                checkpoint = {}
-                checkpoint['state_dict'] = model.state_dict()
-                checkpoint['optimizer'] = optim.state_dict()
-                checkpoint['lr_scheduler'] = lr_scheduler.state_dict()
-                checkpoint['epoch'] = epoch
-                checkpoint['args'] = args
-                checkpoint['current_beta'] = beta
-                checkpoint['losses'] = loss_str
+                checkpoint = dict(state_dict=model.state_dict(), optimizer=optim.state_dict(),
+                                  lr_scheduler=lr_scheduler.state_dict(), epoch=epoch, args=args,
+                                  current_beta=beta, losses=loss_str)   # keys of reference main.py:219-226
                 torch.save(checkpoint, 'checkpoints/' + experiment_str + ".pth")
                 model.sample(name=experiment_str)
         if rank == 0 and not os.path.isfile(args.ae_checkpoint):  # save full model checkpoint

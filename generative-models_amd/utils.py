@@ -7,13 +7,14 @@ import torch.nn as nn
 
 
 def print_debug(x, debug=False, name=''):
-    if debug:
-        print(f'{name} shape: {list(x.shape)}\n\tvalues: {x.flatten()[:8]}')
+    """--debug trace line: shape and the first eight values (format of reference utils.py:13-15)."""
+    if not debug:
+        return
+    print(f'{name} shape: {list(x.shape)}\n\tvalues: {x.flatten()[:8]}')
 
 
 def make_folder(name):
-    if not os.path.isdir(name):
-        os.mkdir(name)
+    os.makedirs(name, exist_ok=True)
 
 
 def _make_grid(images, nrow=8, padding=2, normalize=False):
@@ -61,21 +62,16 @@ def plot_grid(model, input_images=None, name=''):
     save_image_grid(stack, f'plots/{name}.png', nrow=input_images.shape[0], normalize=True)
 
 
+_ACTIVATIONS = {
+    'relu': nn.ReLU, 'leaky-relu': nn.LeakyReLU, 'elu': nn.ELU, 'selu': nn.SELU,
+    'gelu': nn.GELU, 'swish': nn.SiLU, 'mish': nn.Mish,
+}
+
+
 def get_activation_function(act_str):
-    if act_str == 'relu':
-        act = nn.ReLU()
-    elif act_str == 'leaky-relu':
-        act = nn.LeakyReLU()
-    elif act_str == 'elu':
-        act = nn.ELU()
-    elif act_str == 'selu':
-        act = nn.SELU()
-    elif act_str == 'gelu':
-        act = nn.GELU()
-    elif act_str == 'swish':
-        act = nn.SiLU()
-    elif act_str == 'mish':
-        act = nn.Mish()
-    else:
-        raise(NotImplementedError)
-    return act
+    """--act string -> nn.Module instance (same seven names as the reference, utils.py:49-66); the modules are
+    only tokens for gmk.act_id, the kernels apply the activation in their epilogues."""
+    try:
+        return _ACTIVATIONS[act_str]()
+    except KeyError:
+        raise NotImplementedError(act_str) from None
