@@ -108,6 +108,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
   const int bbase = seg * CK * PS + h * PS + (br * SB) * PC + bx * SB;
   const int abase = (wm * MT * 32 + j) * WS + h * KK;
 
+  // patch (row, column) and parity class of tap t
+  auto tap_row = [](int t) constexpr { const int ky = t / KS; return MODE == 2 ? (((ky + PAD) & 1) + PAD - ky) / 2 + TLO : ky; };
+  auto tap_col = [](int t) constexpr { const int kx = t % KS; return MODE == 2 ? (((kx + PAD) & 1) + PAD - kx) / 2 + TLO : kx; };
+  auto tap_cls = [](int t) constexpr { return MODE == 2 ? (((t / KS + PAD) & 1) * 2 + ((t % KS + PAD) & 1)) : 0; };
+  constexpr int NSTEP = (CK / 2) * KK, RPS = 1 + MT, PF = 12 / RPS;
+  static_assert(MT == 1 || MT == 2, "operand ring is written for 1 or 2 channel tiles per wave");
+  const unsigned addrA = gmk_lds_addr(Wl) + (unsigned)abase * 4u;
+  unsigned addrB[CK / 2][KS];
+#pragma unroll
+  for (int cp = 0; cp < CK / 2; ++cp)
+#pragma unroll
+    for (int r = 0; r < KS; ++r) addrB[cp][r] = gmk_lds_addr(Xl) + (unsigned)(bbase + cp * 2 * PS + r * PC) * 4u;
+
   f32x16 acc[NCLS][MT];
 #pragma unroll
   for (int c = 0; c < NCLS; ++c)
@@ -142,7 +155,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
   load_chunk(0);
   const int Cend = (g.dbg & 2) ? 0 : g.C;
   for (int c0 = 0; c0 < Cend; c0 += CK) {
-    __syncthreads();  // previous chunk's LDS reads are done
+    if (!(g.dbg & 4) || c0 == 0) {
+    if (!(g.dbg & 8)) __syncthreads();  // previous chunk's LDS reads are done
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k)
       if (s_loff[k] >= 0) {
@@ -152,32 +166,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
 #pragma unroll
     for (int u = 0; u < NW; ++u)
       if (w_loff[u] >= 0) Wl[w_loff[u]] = wr[u];
-    __syncthreads();
-    if (c0 + CK < g.C) load_chunk(c0 + CK);  // in flight during the MFMA loop below
-    // MFMA over the chunk: k-step = (channel pair cp, tap t); lane half h takes channel 2cp+h
-#pragma unroll
-    for (int cp = 0; cp < CK / 2; ++cp) {
-#pragma unroll
-      for (int t = 0; t < KK; ++t) {
-        const int ky = t / KS, kx = t % KS;
-        int boff, cls;
-        if (MODE == 2) {
-          const int py = (ky + PAD) & 1, px = (kx + PAD) & 1;
-          const int dy = (py + PAD - ky) / 2, dx = (px + PAD - kx) / 2;
-          boff = (dy + TLO) * PC + (dx + TLO);
-          cls = py * 2 + px;
-        } else {
-          boff = ky * PC + kx;
-          cls = 0;
-        }
-        const float b = Xl[bbase + cp * 2 * PS + boff];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const float a = Wl[abase + i * 32 * WS + cp * 2 * KK + t];
-          acc[cls][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc[cls][i], 0, 0, 0);  // rows = pixels, cols = channels
-        }
-      }
+    if (!(g.dbg & 8)) __syncthreads();
+    if (c0 + CK < g.C && !(g.dbg & 16)) load_chunk(c0 + CK);  // in flight during the MFMA loop below
     }
+    // MFMA over the chunk: k-step = (channel pair cp, tap t); lane half h takes channel 2cp+h.  Operands come from LDS
+    // through hand-placed ds_read_b32 (immediate offsets from loop-invariant address registers, no VALU in the loop),
+    // PF k-steps ahead of their MFMAs; the ring of PF+1 register sets is indexed at compile time.
+    float rb[PF + 1], ra[PF + 1][MT];
+    auto issue = [&](auto s_) {
+      constexpr int s = decltype(s_)::value, cp = s / KK, t = s % KK, slot = s % (PF + 1);
+      GMK_DS_READ(rb[slot], addrB[cp][tap_row(t)], tap_col(t) * 4);
+      GMK_DS_READ(ra[slot][0], addrA, (cp * 2 * KK + t) * 4);
+      if constexpr (MT == 2) GMK_DS_READ(ra[slot][1], addrA, (32 * WS + cp * 2 * KK + t) * 4);
+    };
+    gmk_static_for<0, PF>(issue);
+    gmk_static_for<0, NSTEP>([&](auto s_) {
+      constexpr int s = decltype(s_)::value, t = s % KK, slot = s % (PF + 1);
+      if constexpr (s + PF < NSTEP) issue(std::integral_constant<int, s + PF>{});
+      constexpr int ahead = (NSTEP - 1 - s < PF ? NSTEP - 1 - s : PF) * RPS;  // reads issued after this step's
+      if constexpr (MT == 2) GMK_LDS_WAIT3(ahead, rb[slot], ra[slot][0], ra[slot][1]);
+      else GMK_LDS_WAIT2(ahead, rb[slot], ra[slot][0]);
+      constexpr int cls = tap_cls(t);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        acc[cls][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(rb[slot], ra[slot][i], acc[cls][i], 0, 0, 0);  // rows = pixels, cols = channels
+    });
   }
 
   // ---- epilogue ----

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <type_traits>
 #include "../../include/gmk.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -115,6 +116,30 @@ __device__ __forceinline__ float gmk_buffer_load(__amdgpu_buffer_rsrc_t r, int v
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global
 // load (s_waitcnt vmcnt(0)), which serialises register prefetch against the barrier; this one leaves
 // global loads in flight (the compiler still waits on a load's registers before their first use).
+// Compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N).  Used where an index has to be a constant
+// expression (inline-asm immediates).
+template <int I, int N, class F>
+__device__ __forceinline__ void gmk_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    gmk_static_for<I + 1, N>(f);
+  }
+}
+
+// LDS byte address of a __shared__ object (what ds_read / ds_write take as their VGPR operand).
+__device__ __forceinline__ unsigned gmk_lds_addr(const void* p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+// ds_read_b32 with an immediate offset, issued exactly where it is written.  The compiler neither merges these into
+// ds_read2_b32 (which costs fp32-MFMA issue time on gfx950, tools/mfma_ds.hip) nor tracks their completion: the caller
+// waits with GMK_LDS_WAIT* before the first use.
+#define GMK_DS_READ(dst, addr, byte_off) \
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(byte_off) : "memory")
+// s_waitcnt lgkmcnt(n) tied to the registers it protects, so that their consumers cannot be moved above it
+#define GMK_LDS_WAIT2(n, x, y) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(n))
+#define GMK_LDS_WAIT3(n, x, y, z) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(x), "+v"(y), "+v"(z) : "n"(n))
+
 __device__ __forceinline__ void gmk_lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
