@@ -49,8 +49,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
   constexpr int ORG = (MODE == 2) ? TLO : PAD;  // patch origin offset (rows/cols before the base position)
   constexpr int NW = (MB * KC + 255) / 256;     // weight elements staged per thread and chunk
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // LDS: [W tile 0][W tile 1][X patch 0][X patch 1]; chunk i lives in buffer i & 1 and is written while chunk i-1 is multiplied
   float* Wl = smem;
-  float* Xl = smem + MB * WS;
+  float* Xl = smem + 2 * MB * WS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WP, wp = wave % WP;
@@ -68,13 +69,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
   if (nimg > g.nseg + 1) nimg = g.nseg + 1;
   const __amdgpu_buffer_rsrc_t rx = gmk_make_rsrc(g.x + n0 * g.C * (long long)IHW, nimg * g.C * (long long)IHW * 4);
   const __amdgpu_buffer_rsrc_t rw = gmk_make_rsrc(g.w, (long long)g.w_numel * 4);
+  const __amdgpu_buffer_rsrc_t rw0 = gmk_make_rsrc(g.w, 0);  // zero records: every load returns 0
   int s_voff[NSLOT], s_loff[NSLOT];
 #pragma unroll
   for (int k = 0; k < NSLOT; ++k) {
     int e = tid + k * 256;
+    if (e >= g.npos) e = g.npos - 1;  // surplus threads duplicate the last position (same value to the same address)
     s_voff[k] = GMK_OOB;
-    s_loff[k] = -1;
-    if (e < g.npos) {
+    {
       int seg = e / (PR * PC), r = e % (PR * PC);
       int prow = r / PC, pcol = r % PC;
       long long P = p0 + (long long)seg * g.seg_px;
@@ -90,15 +92,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
   int w_voff[NW], w_loff[NW];
 #pragma unroll
   for (int u = 0; u < NW; ++u) {
-    const int e = tid + u * 256;
+    int e = tid + u * 256;
+    if (e >= MB * KC) e = MB * KC - 1;  // surplus threads duplicate the last element
     int m, c, t;
     if (g.w_layout == 0) { m = e / KC; int r = e % KC; c = r / KK; t = r % KK; }
     else { c = e / (MB * KK); int r = e % (MB * KK); m = r / KK; t = r % KK; }
     const int gm = m0 + m;
-    const bool ok = (e < MB * KC) && gm < g.M;
-    w_voff[u] = ok ? (gm * g.w_m_stride + c * g.w_c_stride + t) * 4 : GMK_OOB;
+    w_voff[u] = gm < g.M ? (gm * g.w_m_stride + c * g.w_c_stride + t) * 4 : GMK_OOB;
     const int tt = g.flip ? (KK - 1 - t) : t;
-    w_loff[u] = (e < MB * KC) ? m * WS + c * KK + tt : -1;
+    w_loff[u] = m * WS + c * KK + tt;
   }
 
   // ---- lane bases for the MFMA operand reads ----
@@ -114,12 +116,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
   auto tap_cls = [](int t) constexpr { return MODE == 2 ? (((t / KS + PAD) & 1) * 2 + ((t % KS + PAD) & 1)) : 0; };
   constexpr int NSTEP = (CK / 2) * KK, RPS = 1 + MT, PF = 12 / RPS;
   static_assert(MT == 1 || MT == 2, "operand ring is written for 1 or 2 channel tiles per wave");
-  const unsigned addrA = gmk_lds_addr(Wl) + (unsigned)abase * 4u;
-  unsigned addrB[CK / 2][KS];
+  const int XSZ = g.nseg * CK * PS;  // floats per X patch buffer
+  unsigned addrA[2], addrB[2][CK / 2][KS];
 #pragma unroll
-  for (int cp = 0; cp < CK / 2; ++cp)
+  for (int p = 0; p < 2; ++p) {
+    addrA[p] = gmk_lds_addr(Wl) + (unsigned)(p * MB * WS + abase) * 4u;
 #pragma unroll
-    for (int r = 0; r < KS; ++r) addrB[cp][r] = gmk_lds_addr(Xl) + (unsigned)(bbase + cp * 2 * PS + r * PC) * 4u;
+    for (int cp = 0; cp < CK / 2; ++cp)
+#pragma unroll
+      for (int r = 0; r < KS; ++r)
+        addrB[p][cp][r] = gmk_lds_addr(Xl) + (unsigned)(p * XSZ + bbase + cp * 2 * PS + r * PC) * 4u;
+  }
 
   f32x16 acc[NCLS][MT];
 #pragma unroll
@@ -152,45 +159,80 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
     }
   };
 
+  // Pipeline: chunk 0 is staged up front and chunk 1 is loaded into the staging registers.  Iteration i multiplies
+  // buffer i & 1 and, spread over its k-steps, writes the registers (chunk i+1) into the other buffer and reloads
+  // each register with chunk i+2 right behind its write -- one register set, a full iteration of load latency, one
+  // barrier per chunk.  All of it is straight-line code (exact vmcnt counting); chunks past the end are clamped
+  // to the last one and land in a buffer nobody reads.
+  const int nch = (g.C + CK - 1) / CK;
   load_chunk(0);
-  const int Cend = (g.dbg & 2) ? 0 : g.C;
-  for (int c0 = 0; c0 < Cend; c0 += CK) {
-    if (!(g.dbg & 4) || c0 == 0) {
-    if (!(g.dbg & 8)) __syncthreads();  // previous chunk's LDS reads are done
 #pragma unroll
-    for (int k = 0; k < NSLOT; ++k)
-      if (s_loff[k] >= 0) {
+  for (int k = 0; k < NSLOT; ++k)
 #pragma unroll
-        for (int c = 0; c < CK; ++c) Xl[s_loff[k] + c * PS] = xr[k][c];
+    for (int c = 0; c < CK; ++c) Xl[s_loff[k] + c * PS] = xr[k][c];
+#pragma unroll
+  for (int u = 0; u < NW; ++u) Wl[w_loff[u]] = wr[u];
+  if (nch > 1) load_chunk(CK);
+  else {  // single chunk: the padding chunk of the pair gets zero weights
+#pragma unroll
+    for (int u = 0; u < NW; ++u) wr[u] = 0.f;
+  }
+
+  constexpr int NITEM = NSLOT * CK + NW, IPS = (NITEM + NSTEP - 1) / NSTEP;  // staging items, items per k-step
+  auto chunk_body = [&](auto P_, int i) {
+    constexpr int P = decltype(P_)::value;
+    gmk_lds_barrier();  // buffer P is complete; everybody is done reading buffer P ^ 1 (reloads stay in flight)
+    float* Xw = Xl + (P ^ 1) * XSZ;
+    float* Ww = Wl + (P ^ 1) * MB * WS;
+    const int cn = (i + 2 < nch ? i + 2 : nch - 1) * CK;  // chunk to reload (uniform)
+    int soffc[CK];
+#pragma unroll
+    for (int c = 0; c < CK; ++c) soffc[c] = (cn + c) * IHW * 4;
+    const int wsoff = cn * g.w_c_stride * 4;
+    const __amdgpu_buffer_rsrc_t rwn = (i + 2 < nch) ? rw : rw0;  // uniform select; chunks past the end read zeros
+    auto stage_item = [&](auto q_) {
+      constexpr int q = decltype(q_)::value;
+      if constexpr (q < NSLOT * CK) {
+        constexpr int k = q / CK, c = q % CK;
+        Xw[s_loff[k] + c * PS] = xr[k][c];
+        xr[k][c] = gmk_buffer_load(rx, s_voff[k], soffc[c]);
+      } else if constexpr (q < NITEM) {
+        constexpr int u = q - NSLOT * CK;
+        Ww[w_loff[u]] = wr[u];
+        wr[u] = gmk_buffer_load(rwn, w_voff[u], wsoff);
       }
-#pragma unroll
-    for (int u = 0; u < NW; ++u)
-      if (w_loff[u] >= 0) Wl[w_loff[u]] = wr[u];
-    if (!(g.dbg & 8)) __syncthreads();
-    if (c0 + CK < g.C && !(g.dbg & 16)) load_chunk(c0 + CK);  // in flight during the MFMA loop below
-    }
+    };
     // MFMA over the chunk: k-step = (channel pair cp, tap t); lane half h takes channel 2cp+h.  Operands come from LDS
     // through hand-placed ds_read_b32 (immediate offsets from loop-invariant address registers, no VALU in the loop),
     // PF k-steps ahead of their MFMAs; the ring of PF+1 register sets is indexed at compile time.
     float rb[PF + 1], ra[PF + 1][MT];
     auto issue = [&](auto s_) {
       constexpr int s = decltype(s_)::value, cp = s / KK, t = s % KK, slot = s % (PF + 1);
-      GMK_DS_READ(rb[slot], addrB[cp][tap_row(t)], tap_col(t) * 4);
-      GMK_DS_READ(ra[slot][0], addrA, (cp * 2 * KK + t) * 4);
-      if constexpr (MT == 2) GMK_DS_READ(ra[slot][1], addrA, (32 * WS + cp * 2 * KK + t) * 4);
+      GMK_DS_READ(rb[slot], addrB[P][cp][tap_row(t)], tap_col(t) * 4);
+      GMK_DS_READ(ra[slot][0], addrA[P], (cp * 2 * KK + t) * 4);
+      if constexpr (MT == 2) GMK_DS_READ(ra[slot][1], addrA[P], (32 * WS + cp * 2 * KK + t) * 4);
     };
     gmk_static_for<0, PF>(issue);
     gmk_static_for<0, NSTEP>([&](auto s_) {
       constexpr int s = decltype(s_)::value, t = s % KK, slot = s % (PF + 1);
       if constexpr (s + PF < NSTEP) issue(std::integral_constant<int, s + PF>{});
+      // LDS operations complete in order, so the staging writes issued in between only make this wait stricter
       constexpr int ahead = (NSTEP - 1 - s < PF ? NSTEP - 1 - s : PF) * RPS;  // reads issued after this step's
       if constexpr (MT == 2) GMK_LDS_WAIT3(ahead, rb[slot], ra[slot][0], ra[slot][1]);
       else GMK_LDS_WAIT2(ahead, rb[slot], ra[slot][0]);
       constexpr int cls = tap_cls(t);
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-        acc[cls][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(rb[slot], ra[slot][i], acc[cls][i], 0, 0, 0);  // rows = pixels, cols = channels
+      for (int i2 = 0; i2 < MT; ++i2)
+        acc[cls][i2] = __builtin_amdgcn_mfma_f32_32x32x2f32(rb[slot], ra[slot][i2], acc[cls][i2], 0, 0, 0);  // rows = pixels, cols = channels
+      gmk_static_for<s * IPS, (s + 1) * IPS>(stage_item);
     });
+  };
+  // Chunks go in pairs (buffer 0, buffer 1) so that the buffer index is a compile-time constant; an odd chunk count is
+  // padded with one chunk whose weights are all zero (loaded through the empty descriptor rw0).
+  const int nloop = (g.dbg & 2) ? 0 : nch;
+  for (int i = 0; i < nloop; i += 2) {
+    chunk_body(std::integral_constant<int, 0>{}, i);
+    chunk_body(std::integral_constant<int, 1>{}, i + 1);
   }
 
   // ---- epilogue ----
@@ -310,7 +352,9 @@ static int gmk_launch_conv_impl(ConvGeom& g, int mode, hipStream_t s) {
   g.npos = g.nseg * g.PR * g.PC;
   if (g.npos > 256 * (mode == 1 ? 4 : 2)) return GMK_E_SHAPE;
   (void)BH;
-  size_t lds = sizeof(float) * ((size_t)MB * ((CK * KK) | 1) + (size_t)g.nseg * CK * g.PS);
+  // a ragged chunk (C % CK != 0) is loaded with channel masks, which only the up-front loads of chunks 0 and 1 apply
+  if (g.C % CK != 0 && (g.C + CK - 1) / CK > 2) return GMK_E_SHAPE;
+  size_t lds = 2 * sizeof(float) * ((size_t)MB * ((CK * KK) | 1) + (size_t)g.nseg * CK * g.PS);  // double-buffered
   const size_t lds_epi = sizeof(float) * 4 * 32 * ((mode == 2 ? 64 : 32) + 4);  // per-wave transpose tiles of the epilogue
   if (lds < lds_epi) lds = lds_epi;
   if (lds > 160 * 1024) return GMK_E_SHAPE;
