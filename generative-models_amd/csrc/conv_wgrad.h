@@ -106,9 +106,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  // bias-gradient partial: thread (channel tid & 31, part tid >> 5) sums 1/8 of the chunk's dY pixels
-  float bsum = 0.f;
-  const int bch = tid & 31, bpart = tid >> 5;
+  // bias-gradient partials, taken from the staging registers on their way to LDS: every staging slot of a thread
+  // belongs to one fixed channel, so each slot keeps a running sum (bias_mode 1: dY is the small tensor -> S quads;
+  // 2: dY is the big tensor -> the interior rows of the B patch, the halo rows belong to neighbouring chunks); the
+  // per-slot sums are combined per channel in a fixed order after the main loop.
   const bool bias1 = g.bias_mode == 1 && tg == 0 && (tile % g.cbT) == 0;  // only the blocks the reduce kernel reads
   const bool bias2 = g.bias_mode == 2 && tg == 0 && (tile / g.cbT) == 0;
 
@@ -147,8 +148,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
 #pragma unroll
   for (int m = 0; m < 4; ++m) bbase[m] = Bl + jj * PSb + ((lc + m) ^ asw);  // + (K & ~3) for K & 3 == m
 
-  float4 sr[NS];
-  float4 br[NSLOT];
+  f32x4 sr[NS];  // prefetch registers (gmk_gload_f4_async)
+  f32x4 br[NSLOT];
+  float bs_s[NS], bs_b[NSLOT];
+#pragma unroll
+  for (int u = 0; u < NS; ++u) bs_s[u] = 0.f;
+#pragma unroll
+  for (int k = 0; k < NSLOT; ++k) bs_b[k] = 0.f;
   // branch-free batched loads of one pixel chunk into registers (a chunk index past the end re-reads the
   // last chunk; its contribution is skipped).  Patch rows outside the image re-read a valid quad, zeroed on the way
   // to LDS.
@@ -167,23 +173,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
       const int e = tid + u * 256;
       const int c = e / (PX / 4), p4 = e % (PX / 4);
       const int cc = c < cmax_s ? c : cmax_s - 1;  // ragged tile: re-read a valid channel, zeroed on the way to LDS
-      sr[u] = *(const float4*)(sbase + ((size_t)cc << g.lgSHW) + p4 * 4);
+      gmk_gload_f4_async(sr[u], sbase + ((size_t)cc << g.lgSHW) + p4 * 4);
     }
     const float* bbase_g = g.b + (n * g.Cb + cb0) * (long long)BHW + (long long)(r0 * SB) * BWt;
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k) {
       const int iy = r0 * SB + (q_meta[k] & 0xFF) - PAD;
       const bool ok = (q_meta[k] != 0x3FF) & (iy >= 0) & (iy < g.BHt);
-      br[k] = *(const float4*)(bbase_g + (ok ? q_goff[k] : 0));
+      gmk_gload_f4_async(br[k], bbase_g + (ok ? q_goff[k] : 0));
     }
   };
   auto store_chunk = [&]() {
+    gmk_vm_wait_all();  // issued a whole MFMA section ago
+#pragma unroll
+    for (int u = 0; u < NS; ++u) gmk_pin(sr[u]);
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) gmk_pin(br[k]);
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
       const int e = tid + u * 256;
       const int c = e / (PX / 4), p4 = e % (PX / 4);
       const int sw = (c >> 3) & 3;
-      float4 v = sr[u];
+      float4 v = make_float4(sr[u].x, sr[u].y, sr[u].z, sr[u].w);
       if (c >= cmax_s) v = make_float4(0.f, 0.f, 0.f, 0.f);
       // element k of the quad goes to slot k ^ sw
       const float4 w1 = (sw & 1) ? make_float4(v.y, v.x, v.w, v.z) : v;
@@ -195,10 +206,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
       const int iy = cur_r0 * SB + (q_meta[k] & 0xFF) - PAD;
       const bool ok = (q_meta[k] != 0x3FF) & (iy >= 0) & (iy < g.BHt);
       const int sw = (q_meta[k] >> 8) & 3;
-      float4 v = ok ? br[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v = ok ? make_float4(br[k].x, br[k].y, br[k].z, br[k].w) : make_float4(0.f, 0.f, 0.f, 0.f);
       const float4 w1 = (sw & 1) ? make_float4(v.y, v.x, v.w, v.z) : v;
       const float4 w2 = (sw & 2) ? make_float4(w1.z, w1.w, w1.x, w1.y) : w1;
       *(float4*)(Bl + q_loff[k]) = w2;
+    }
+    if (bias1) {
+#pragma unroll
+      for (int u = 0; u < NS; ++u) bs_s[u] += (sr[u].x + sr[u].y) + (sr[u].z + sr[u].w);
+    }
+    if (bias2) {
+#pragma unroll
+      for (int k = 0; k < NSLOT; ++k) {
+        const int prow = q_meta[k] & 0xFF;  // 0xFF for a dead slot
+        const bool interior = prow >= PAD && prow < PAD + (PX >> LGSW) * SB;
+        bs_b[k] += interior ? (br[k].x + br[k].y) + (br[k].z + br[k].w) : 0.f;
+      }
     }
   };
 
@@ -209,24 +232,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
     store_chunk();
     gmk_lds_barrier();
     load_chunk(ch + g.G);  // next chunk in flight under the MFMAs
-    // bias gradient: per-channel sum of dY over this chunk (bias_mode 1: dY is the small tensor,
-    // 2: dY is the big tensor -> interior of the patch only, the halo belongs to neighbouring chunks)
-    if (bias1) {
-      float v[PX / 8];
-#pragma unroll
-      for (int k = 0; k < PX / 8; ++k) {
-        const int p = bpart * (PX / 8) + k;
-        v[k] = Sl[bch * SS + (p ^ ((bch >> 3) & 3))];
-      }
-#pragma unroll
-      for (int k = 0; k < PX / 8; ++k) bsum += v[k];
-    } else if (bias2) {
-      constexpr int cnt = ((PX >> LGSW) * SB) * BWt;  // interior pixels of the patch, split 8 ways
-      for (int q = bpart; q < cnt; q += 8) {
-        const int r = q / BWt, x = q % BWt;
-        bsum += Bl[bch * PSb + (((r + PAD) * PC + 4 + x) ^ ((bch >> 3) & 3))];
-      }
-    }
     // MFMA over this wave's pixels: fully unrolled, every operand address = per-lane base + immediate
 #pragma unroll
     for (int s2 = 0; s2 < WPX / 2; ++s2) {
@@ -282,14 +287,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
     *(float4*)(out + e) = r0;
   }
   __syncthreads();
-  // bias partials: 8 parts per channel, summed in a fixed order
-  R[bpart * T + bch] = bsum;
+  // bias partials: per-slot sums -> LDS (indexed by staging element), then one thread per channel adds its
+  // channel's contiguous run of elements in a fixed order
+  if (bias1 || bias2) {
+    if (bias1) {
+#pragma unroll
+      for (int u = 0; u < NS; ++u) R[tid + u * 256] = bs_s[u];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NSLOT; ++k) R[tid + k * 256] = bs_b[k];
+    }
+  }
   __syncthreads();
   if (tid < T) {
-    float s = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) s += R[q * T + tid];
-    out[TILE + tid] = s;
+    float sum = 0.f;
+    if (bias1) {
+#pragma unroll 8
+      for (int q = 0; q < PX / 4; ++q) sum += R[tid * (PX / 4) + q];
+    } else if (bias2) {
+#pragma unroll 8
+      for (int q = 0; q < NPOS; ++q) sum += R[tid * NPOS + q];
+    }
+    out[TILE + tid] = sum;
   }
 }
 

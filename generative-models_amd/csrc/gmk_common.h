@@ -116,6 +116,16 @@ __device__ __forceinline__ float gmk_buffer_load(__amdgpu_buffer_rsrc_t r, int v
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global
 // load (s_waitcnt vmcnt(0)), which serialises register prefetch against the barrier; this one leaves
 // global loads in flight (the compiler still waits on a load's registers before their first use).
+// 16-byte global load issued exactly where it is written, for software prefetch across a loop iteration.  A plain
+// load whose first use is in the next iteration gets sunk behind the MFMA section (machine-sink) or delayed by the
+// scheduler, which exposes the whole HBM latency once per chunk.  The compiler does not track these loads: wait with
+// gmk_vm_wait_all() and pass every destination through gmk_pin() before its first use.
+__device__ __forceinline__ void gmk_gload_f4_async(f32x4& dst, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void gmk_vm_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void gmk_pin(f32x4& v) { asm volatile("" : "+v"(v)); }
+
 // Compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N).  Used where an index has to be a constant
 // expression (inline-asm immediates).
 template <int I, int N, class F>
