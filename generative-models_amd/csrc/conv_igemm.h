@@ -137,8 +137,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
       for (int r = 0; r < 16; ++r) acc[c][i][r] = 0.f;
 
   float xr[NSLOT][CK], wr[NW];
-  // branch-free batched loads of one K-chunk into registers
-  auto load_chunk = [&](int c0) {
+  // Batched loads of one K-chunk into the staging registers.  Full chunks need no masks; the ragged tail chunk
+  // (C % CK channels) masks the channels beyond C on both operands.
+  auto load_full = [&](int c0) {
+#pragma unroll
+    for (int c = 0; c < CK; ++c) {
+      const int soff = (c0 + c) * IHW * 4;
+#pragma unroll
+      for (int k = 0; k < NSLOT; ++k) xr[k][c] = gmk_buffer_load(rx, s_voff[k], soff);
+    }
+    const int wsoff = c0 * g.w_c_stride * 4;
+#pragma unroll
+    for (int u = 0; u < NW; ++u) wr[u] = gmk_buffer_load(rw, w_voff[u], wsoff);
+  };
+  auto load_tail = [&](int c0) {
 #pragma unroll
     for (int c = 0; c < CK; ++c) {
       const bool cok = c0 + c < g.C;  // uniform
@@ -147,35 +159,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
       for (int k = 0; k < NSLOT; ++k) xr[k][c] = gmk_buffer_load(rx, cok ? s_voff[k] : GMK_OOB, soff);
     }
     const int wsoff = c0 * g.w_c_stride * 4;
-    if (c0 + CK <= g.C) {
 #pragma unroll
-      for (int u = 0; u < NW; ++u) wr[u] = gmk_buffer_load(rw, w_voff[u], wsoff);
-    } else {  // ragged last chunk: mask the channels beyond C (channel index recovered from the LDS offset)
-#pragma unroll
-      for (int u = 0; u < NW; ++u) {
-        const int c = (w_loff[u] % WS) / KK;
-        wr[u] = gmk_buffer_load(rw, (c0 + c < g.C) ? w_voff[u] : GMK_OOB, wsoff);
-      }
+    for (int u = 0; u < NW; ++u) {
+      const int c = (w_loff[u] % WS) / KK;  // channel of this element, recovered from its LDS offset
+      wr[u] = gmk_buffer_load(rw, (c0 + c < g.C) ? w_voff[u] : GMK_OOB, wsoff);
     }
   };
+  auto write_buf0 = [&]() {
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k)
+#pragma unroll
+      for (int c = 0; c < CK; ++c) Xl[s_loff[k] + c * PS] = xr[k][c];
+#pragma unroll
+    for (int u = 0; u < NW; ++u) Wl[w_loff[u]] = wr[u];
+  };
 
-  // Pipeline: chunk 0 is staged up front and chunk 1 is loaded into the staging registers.  Iteration i multiplies
-  // buffer i & 1 and, spread over its k-steps, writes the registers (chunk i+1) into the other buffer and reloads
-  // each register with chunk i+2 right behind its write -- one register set, a full iteration of load latency, one
-  // barrier per chunk.  All of it is straight-line code (exact vmcnt counting); chunks past the end are clamped
-  // to the last one and land in a buffer nobody reads.
-  const int nch = (g.C + CK - 1) / CK;
-  load_chunk(0);
+  // Pipeline over the full chunks: chunk 0 is staged up front and chunk 1 is loaded into the staging registers.
+  // Iteration i multiplies buffer i & 1 and, spread over its k-steps, writes the registers (chunk i+1) into the other
+  // buffer and reloads each register with chunk i+2 right behind its write -- one register set, a full iteration of
+  // load latency, one barrier per chunk.  All of it is straight-line code (exact vmcnt counting); chunks past the end
+  // are clamped to the last one and land in a buffer nobody reads.
+  const int nch = g.C / CK;            // full chunks
+  const int tail_c0 = nch * CK;        // first channel of the ragged tail chunk (== C if there is none)
+  if (nch > 0) {
+    load_full(0);
+    write_buf0();
+    if (nch > 1) load_full(CK);
+    else {  // single chunk: the padding chunk of the pair gets zero weights
 #pragma unroll
-  for (int k = 0; k < NSLOT; ++k)
-#pragma unroll
-    for (int c = 0; c < CK; ++c) Xl[s_loff[k] + c * PS] = xr[k][c];
-#pragma unroll
-  for (int u = 0; u < NW; ++u) Wl[w_loff[u]] = wr[u];
-  if (nch > 1) load_chunk(CK);
-  else {  // single chunk: the padding chunk of the pair gets zero weights
-#pragma unroll
-    for (int u = 0; u < NW; ++u) wr[u] = 0.f;
+      for (int u = 0; u < NW; ++u) wr[u] = 0.f;
+    }
   }
 
   constexpr int NITEM = NSLOT * CK + NW, IPS = (NITEM + NSTEP - 1) / NSTEP;  // staging items, items per k-step
@@ -233,6 +246,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
   for (int i = 0; i < nloop; i += 2) {
     chunk_body(std::integral_constant<int, 0>{}, i);
     chunk_body(std::integral_constant<int, 1>{}, i + 1);
+  }
+  // Ragged tail (C % CK channels, e.g. the 3 image channels): one masked chunk through buffer 0, compiler-scheduled
+  if (tail_c0 < g.C && !(g.dbg & 2)) {
+    __syncthreads();  // the pipeline's LDS reads and staging writes are done
+    load_tail(tail_c0);
+    write_buf0();
+    __syncthreads();
+#pragma unroll
+    for (int cp = 0; cp < CK / 2; ++cp) {
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        const float b = Xl[bbase + cp * 2 * PS + tap_row(t) * PC + tap_col(t)];
+#pragma unroll
+        for (int i2 = 0; i2 < MT; ++i2) {
+          const float a = Wl[abase + i2 * 32 * WS + cp * 2 * KK + t];
+          acc[tap_cls(t)][i2] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc[tap_cls(t)][i2], 0, 0, 0);
+        }
+      }
+    }
   }
 
   // ---- epilogue ----
@@ -352,8 +384,6 @@ static int gmk_launch_conv_impl(ConvGeom& g, int mode, hipStream_t s) {
   g.npos = g.nseg * g.PR * g.PC;
   if (g.npos > 256 * (mode == 1 ? 4 : 2)) return GMK_E_SHAPE;
   (void)BH;
-  // a ragged chunk (C % CK != 0) is loaded with channel masks, which only the up-front loads of chunks 0 and 1 apply
-  if (g.C % CK != 0 && (g.C + CK - 1) / CK > 2) return GMK_E_SHAPE;
   size_t lds = 2 * sizeof(float) * ((size_t)MB * ((CK * KK) | 1) + (size_t)g.nseg * CK * g.PS);  // double-buffered
   const size_t lds_epi = sizeof(float) * 4 * 32 * ((mode == 2 ? 64 : 32) + 4);  // per-wave transpose tiles of the epilogue
   if (lds < lds_epi) lds = lds_epi;

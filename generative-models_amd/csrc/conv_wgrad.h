@@ -148,6 +148,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
 #pragma unroll
   for (int m = 0; m < 4; ++m) bbase[m] = Bl + jj * PSb + ((lc + m) ^ asw);  // + (K & ~3) for K & 3 == m
 
+  static_assert(NT == 9 || NT == 5, "operand wait lists are written for 9 (3x3) or 5 (one 5x5 tap row) taps per block");
+  unsigned addrA[2], addrB[4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) addrA[m] = gmk_lds_addr(abase[m]);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) addrB[m] = gmk_lds_addr(bbase[m]);
   f32x4 sr[NS];  // prefetch registers (gmk_gload_f4_async)
   f32x4 br[NSLOT];
   float bs_s[NS], bs_b[NSLOT];
@@ -232,21 +238,46 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
     store_chunk();
     gmk_lds_barrier();
     load_chunk(ch + g.G);  // next chunk in flight under the MFMAs
-    // MFMA over this wave's pixels: fully unrolled, every operand address = per-lane base + immediate
-#pragma unroll
-    for (int s2 = 0; s2 < WPX / 2; ++s2) {
-      const float av = abase[s2 & 1][(2 * s2) & ~3];
-      // local pixel 2*s2 of the wave -> (row, column) relative to the wave's first pixel
-      const int lr = (WPX >= SW) ? (2 * s2) >> LGSW : 0;
-      const int lcx = (WPX >= SW) ? (2 * s2) & (SW - 1) : 2 * s2;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int ky = (NT == KK) ? t / KS : 0, kx = (NT == KK) ? t % KS : t;
-        const int K = (lr * SB + ky) * PC + lcx * SB + kx + 4 - PAD;  // a compile-time constant after unrolling
-        const float bv = bbase[K & 3][K & ~3];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+    // MFMA over this wave's pixels: fully unrolled, every operand address = per-lane base + immediate.  The reads are
+    // hand-placed ds_read_b32 one k-step (1 + NT reads) ahead of their MFMAs: left to the compiler they are merged into
+    // ds_read2_b32 (which costs fp32-MFMA issue time on gfx950) and sunk next to their use.
+    float ra[2], rbv[2][NT];
+    auto read_one = [&](auto idx_) {  // read r of k-step s2: r = 0 the S operand, r = 1 + t the patch operand of tap t
+      constexpr int idx = decltype(idx_)::value, s2 = idx / (1 + NT), r = idx % (1 + NT), slot = s2 & 1;
+      (void)ra; (void)rbv; (void)addrA; (void)addrB;  // capture them (their only uses sit in if-constexpr branches)
+      if constexpr (r == 0) {
+        GMK_DS_READ(ra[slot], addrA[s2 & 1], ((2 * s2) & ~3) * 4);
+      } else {
+        // local pixel 2*s2 of the wave -> (row, column) relative to the wave's first pixel
+        constexpr int lr = (WPX >= SW) ? (2 * s2) >> LGSW : 0;
+        constexpr int lcx = (WPX >= SW) ? (2 * s2) & (SW - 1) : 2 * s2;
+        constexpr int t = r - 1, ky = (NT == KK) ? t / KS : 0, kx = (NT == KK) ? t % KS : t;
+        constexpr int K = (lr * SB + ky) * PC + lcx * SB + kx + 4 - PAD;
+        GMK_DS_READ(rbv[slot][t], addrB[K & 3], (K & ~3) * 4);
       }
-    }
+    };
+    auto issue = [&](auto s_) {
+      constexpr int s2 = decltype(s_)::value;
+      gmk_static_for<s2 * (1 + NT), (s2 + 1) * (1 + NT)>(read_one);
+    };
+    issue(std::integral_constant<int, 0>{});
+    gmk_static_for<0, WPX / 2>([&](auto s_) {
+      constexpr int s2 = decltype(s_)::value, slot = s2 & 1;
+      if constexpr (s2 + 1 < WPX / 2) issue(std::integral_constant<int, s2 + 1>{});
+      constexpr int ahead = (s2 + 1 < WPX / 2) ? 1 + NT : 0;
+      if constexpr (NT == 9)
+        asm volatile("s_waitcnt lgkmcnt(%10)"
+                     : "+v"(ra[slot]), "+v"(rbv[slot][0]), "+v"(rbv[slot][1]), "+v"(rbv[slot][2]), "+v"(rbv[slot][3]),
+                       "+v"(rbv[slot][4]), "+v"(rbv[slot][5]), "+v"(rbv[slot][6]), "+v"(rbv[slot][7]), "+v"(rbv[slot][8])
+                     : "n"(ahead));
+      else
+        asm volatile("s_waitcnt lgkmcnt(%6)"
+                     : "+v"(ra[slot]), "+v"(rbv[slot][0]), "+v"(rbv[slot][1]), "+v"(rbv[slot][2]), "+v"(rbv[slot][3]),
+                       "+v"(rbv[slot][4])
+                     : "n"(ahead));
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[slot], rbv[slot][t], acc[t], 0, 0, 0);
+    });
   }
 
   // ---- combine the four waves' partial tiles in LDS (fixed order), one slab per block ----
@@ -318,30 +349,50 @@ template <int KS, int NT>
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                                 float* __restrict__ dbias, int G, int ny, int Cs,
                                                                 int Cb, int cbT, int bias_mode) {
+  // One thread owns 4 consecutive slab elements (16-byte loads), 8 threads split the G slabs of those elements:
+  // few, fat blocks, because this kernel usually has to squeeze into what a large dgrad kernel of the main stream
+  // leaves free on the CUs (many thin blocks took 35-40 us there instead of 4).
   constexpr int KK = KS * KS, NTG = KK / NT, T = GMK_WG_T, TILE = NT * T * T, SLAB = TILE + T;
-  __shared__ float red[8][32];
+  static_assert(TILE % 4 == 0 && SLAB % 4 == 0, "slabs are read as float4");
+  __shared__ float4 red[8][32];
   const int y = blockIdx.y;  // (tile, tg)
   const int tg = y % NTG, tile = y / NTG;
   const int cs0 = (tile / cbT) * T, cb0 = (tile % cbT) * T;
   const int el = threadIdx.x & 31, gq = threadIdx.x >> 5;
-  const int e = blockIdx.x * 32 + el;  // element of the slab (incl. the bias tail)
-  float sum = 0.f;
+  const int e = (blockIdx.x * 32 + el) * 4;  // first of this thread's 4 elements (the bias tail included)
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e < SLAB) {
-#pragma unroll 4
-    for (int gI = gq; gI < G; gI += 8) sum += slab[((size_t)gI * ny + y) * (size_t)SLAB + e];
+    const float* src = slab + ((size_t)gq * ny + y) * (size_t)SLAB + e;
+    const size_t step = (size_t)8 * ny * SLAB;
+#pragma unroll 2
+    for (int gI = gq; gI < G; gI += 8, src += step) {
+      const float4 v = *(const float4*)src;
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
   }
   red[gq][el] = sum;
   __syncthreads();
   if (gq != 0 || e >= SLAB) return;
-  sum = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) + ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
+  auto add4 = [](const float4 a, const float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+  const float4 lo = add4(add4(red[0][el], red[1][el]), add4(red[2][el], red[3][el]));
+  const float4 hi = add4(add4(red[4][el], red[5][el]), add4(red[6][el], red[7][el]));
+  const float4 tot = add4(lo, hi);
+  const float out[4] = {tot.x, tot.y, tot.z, tot.w};
   if (e < TILE) {
-    const int t = e / (T * T), cs = (e / T) % T, cb = e % T;
-    if (cs0 + cs < Cs && cb0 + cb < Cb) dw[((size_t)(cs0 + cs) * Cb + cb0 + cb) * KK + tg * NT + t] = sum;
+    const int t = e / (T * T), cs = (e / T) % T, cb = e % T;  // the 4 elements share t and cs (T % 4 == 0)
+    if (cs0 + cs < Cs) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (cb0 + cb + k < Cb) dw[((size_t)(cs0 + cs) * Cb + cb0 + cb + k) * KK + tg * NT + t] = out[k];
+    }
   } else if (dbias && tg == 0) {
     const int c = e - TILE;
     // bias_mode 1: channel of the small tensor (only the cbTile == 0 blocks carry it); 2: of the big tensor
-    if (bias_mode == 1 && (tile % cbT) == 0 && cs0 + c < Cs) dbias[cs0 + c] = sum;
-    if (bias_mode == 2 && (tile / cbT) == 0 && cb0 + c < Cb) dbias[cb0 + c] = sum;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (bias_mode == 1 && (tile % cbT) == 0 && cs0 + c + k < Cs) dbias[cs0 + c + k] = out[k];
+      if (bias_mode == 2 && (tile / cbT) == 0 && cb0 + c + k < Cb) dbias[cb0 + c + k] = out[k];
+    }
   }
 }
 
@@ -397,7 +448,7 @@ static int gmk_launch_wgrad_impl(WgradGeom& g, int sb, float* dw, float* dbias, 
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   constexpr int SLAB = NT * T * T + T;
-  hipLaunchKernelGGL((conv_wgrad_reduce_kernel<KS, NT>), dim3((SLAB + 31) / 32, grid.y), dim3(256), 0, s, g.slab, dw,
+  hipLaunchKernelGGL((conv_wgrad_reduce_kernel<KS, NT>), dim3((SLAB + 127) / 128, grid.y), dim3(256), 0, s, g.slab, dw,
                      dbias, g.G, (int)grid.y, g.Cs, g.Cb, g.cbT, g.bias_mode);
   e = hipGetLastError();
   return e == hipSuccess ? GMK_OK : (int)e;

@@ -49,6 +49,12 @@ CONV_SHAPES = [
     (1, 16, 64, 64, 16, 3, 1),
     (16, 64, 16, 16, 64, 3, 1),   # enough base positions for the 64x128 tile
     (3, 24, 8, 8, 40, 3, 1),      # ragged channel counts
+    # channel counts that are not a multiple of the 8-channel K-chunk: pipelined full chunks + masked tail chunk,
+    # odd / even numbers of full chunks (zero-weight padding chunk), stride 1 and 2 (dgrad runs the other modes)
+    (2, 20, 16, 16, 12, 3, 1),
+    (2, 100, 16, 16, 36, 3, 2),
+    (2, 28, 16, 16, 12, 3, 2),
+    (1, 9, 8, 8, 17, 3, 1),
     # thin-channel wgrad kernel (conv_wgrad_thin.h): thin input / thin output, ragged + multi-tile wide side, k=5,
     # 64x64 images, and enough 256-pixel chunks (N*H*W/256 > 256 blocks) for several double-buffered iterations
     (3, 3, 64, 64, 16, 3, 1),
@@ -118,7 +124,8 @@ def test_conv2d_dgrad_wgrad(shape):
     close(db, gb, name="db")
 
 
-DECONV_SHAPES = [(2, 64, 8, 8, 64, 3), (2, 64, 16, 16, 64, 3), (3, 16, 8, 8, 24, 3), (1, 8, 8, 8, 8, 5), (9, 64, 16, 16, 64, 3)]
+DECONV_SHAPES = [(2, 64, 8, 8, 64, 3), (2, 64, 16, 16, 64, 3), (3, 16, 8, 8, 24, 3), (1, 8, 8, 8, 8, 5), (9, 64, 16, 16, 64, 3),
+                 (2, 20, 8, 8, 12, 3), (2, 44, 16, 16, 100, 3)]  # K-chunk tails in every mode
 
 
 @pytest.mark.parametrize("shape", DECONV_SHAPES)
