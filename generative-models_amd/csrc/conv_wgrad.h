@@ -33,6 +33,7 @@ struct WgradGeom {
   int G;               // pixel-chunk groups (gridDim.x)
   int csT, cbT;        // 32-channel tiles
   int bias_mode;       // 0 none, 1 dY = small tensor, 2 dY = big tensor
+  int dbg;             // profiling ablations (GMK_WG_DBG, 0 in production): 4 = no final reduction, 8 = no chunk loop
 };
 
 #define GMK_WG_T 32  // channel tile (both sides)
@@ -63,9 +64,7 @@ constexpr WgradPatch gmk_wgrad_patch_for(int p, int SW, int ksize, int sb) {
 #ifndef GMK_WG_MAXPX_S2
 #define GMK_WG_MAXPX_S2 64
 #endif
-#ifndef GMK_WG_RED_REGIONS
-#define GMK_WG_RED_REGIONS 2  /* partial tiles parked in LDS at once by the in-block reduction (4, 2 or 1) */
-#endif
+#define GMK_WG_RED_STRIDE 36  /* row stride (floats) of the transposed partial tiles parked in LDS by the in-block reduction */
 constexpr WgradPatch gmk_wgrad_patch(int SW, int ksize, int sb) {
   int p = sb == 1 ? GMK_WG_MAXPX_S1 : GMK_WG_MAXPX_S2;
   if (p > SW * SW) p = SW * SW;
@@ -232,6 +231,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
   };
 
   long long ch = blockIdx.x;
+  if (g.dbg & 8) ch = g.total_chunks;
   load_chunk(ch);
   for (; ch < g.total_chunks; ch += g.G) {
     gmk_lds_barrier();  // previous chunk's LDS reads are done
@@ -280,42 +280,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
     });
   }
 
+  if (g.dbg & 4) return;
   // ---- combine the four waves' partial tiles in LDS (fixed order), one slab per block ----
-  // slab[(blockIdx.x * gridDim.y + blockIdx.y)][t][cs 32][cb 32] followed by 32 bias partials
-  constexpr int TILE = NT * T * T, SLAB = TILE + T;
-  // The four waves' partial tiles are summed in the fixed order (w0 + w1) + (w2 + w3) ... through RR regions of LDS:
-  // RR = 4: every wave parks its tile, one barrier; RR = 2 / 1: in rounds (less LDS, so that blocks of other kernels
-  // can share the CU).
-  constexpr int RR = GMK_WG_RED_REGIONS;
-  float* R = smem;  // [RR][TILE]
+  // slab[(blockIdx.x * gridDim.y + blockIdx.y)][t][cb 32][cs 32] followed by 32 bias partials.
+  // A lane's accumulator quad (registers 4q .. 4q+3) is four consecutive cs of one cb, so with the tile kept
+  // TRANSPOSED ([t][cb][cs], rows padded to 36 floats: 16-byte accesses of 8 consecutive lanes hit distinct banks)
+  // every exchange is a ds_*_b128: 36 per lane and round instead of 144 dword accesses (this reduction was 11 us of
+  // every launch).  Fixed order (w0 + w2) + (w1 + w3) through two regions: waves 0,1 park their tiles, waves 2,3 add theirs.
+  constexpr int TILE = NT * T * T, SLAB = TILE + T, RS = GMK_WG_RED_STRIDE, RG = NT * T * RS;
+  float* R = smem;  // [2][NT][32][RS]
 #pragma unroll 1
-  for (int ph = 0; ph < 4 / RR; ++ph) {
+  for (int ph = 0; ph < 2; ++ph) {
     __syncthreads();
-    if (wave / RR == ph) {
-      float* Rw = R + (wave % RR) * TILE;
+    if ((wave >> 1) == ph) {
+      float* Rw = R + (wave & 1) * RG + jj * RS + 4 * h;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int cs = (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int idx = (t * T + cs) * T + jj;
-          Rw[idx] = (ph == 0) ? acc[t][r] : Rw[idx] + acc[t][r];
+        for (int q = 0; q < 4; ++q) {
+          float4* p = (float4*)(Rw + t * T * RS + 8 * q);
+          float4 v = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+          if (ph == 1) {
+            const float4 o = *p;
+            v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+          }
+          *p = v;
         }
     }
   }
   __syncthreads();
   float* out = g.slab + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (size_t)SLAB;
   for (int e = tid * 4; e < TILE; e += 1024) {
-    float4 r0 = *(const float4*)(R + e);
-    if (RR >= 2) {
-      const float4 r1 = *(const float4*)(R + TILE + e);
-      r0 = make_float4(r0.x + r1.x, r0.y + r1.y, r0.z + r1.z, r0.w + r1.w);
-    }
-    if (RR == 4) {
-      const float4 r2 = *(const float4*)(R + 2 * TILE + e), r3 = *(const float4*)(R + 3 * TILE + e);
-      r0 = make_float4(r0.x + (r2.x + r3.x), r0.y + (r2.y + r3.y), r0.z + (r2.z + r3.z), r0.w + (r2.w + r3.w));
-    }
-    *(float4*)(out + e) = r0;
+    const int row = e >> 5, col = e & 31;  // (t * 32 + cb, cs)
+    const float4 r0 = *(const float4*)(R + row * RS + col), r1 = *(const float4*)(R + RG + row * RS + col);
+    *(float4*)(out + e) = make_float4(r0.x + r1.x, r0.y + r1.y, r0.z + r1.z, r0.w + r1.w);
   }
   __syncthreads();
   // bias partials: per-slot sums -> LDS (indexed by staging element), then one thread per channel adds its
@@ -343,7 +341,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
   }
 }
 
-// dW[cs][cb][t] = sum_g slab[g][tile,tg][t][cs][cb]   (fixed order: 8 interleaved partial sums over g,
+// dW[cs][cb][t] = sum_g slab[g][tile,tg][t][cb][cs]   (fixed order: 8 interleaved partial sums over g,
 // combined in a fixed tree) ; dbias likewise from the 32 trailing floats of each slab.
 template <int KS, int NT>
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
@@ -379,11 +377,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
   const float4 tot = add4(lo, hi);
   const float out[4] = {tot.x, tot.y, tot.z, tot.w};
   if (e < TILE) {
-    const int t = e / (T * T), cs = (e / T) % T, cb = e % T;  // the 4 elements share t and cs (T % 4 == 0)
-    if (cs0 + cs < Cs) {
+    const int t = e / (T * T), cb = (e / T) % T, cs = e % T;  // slabs are [t][cb][cs]: the 4 elements share t and cb
+    if (cb0 + cb < Cb) {
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (cb0 + cb + k < Cb) dw[((size_t)(cs0 + cs) * Cb + cb0 + cb + k) * KK + tg * NT + t] = out[k];
+        if (cs0 + cs + k < Cs) dw[((size_t)(cs0 + cs + k) * Cb + cb0 + cb) * KK + tg * NT + t] = out[k];
     }
   } else if (dbias && tg == 0) {
     const int c = e - TILE;
@@ -416,7 +414,7 @@ static int gmk_launch_wgrad_impl(WgradGeom& g, int sb, float* dw, float* dbias, 
   const WgradPatch w = gmk_wgrad_patch(g.SW, KS, sb);
   if (w.PX != g.P) return GMK_E_SHAPE;
   size_t lds = w.lds;
-  const size_t red = sizeof(float) * GMK_WG_RED_REGIONS * NT * T * T;  // parked partial tiles
+  const size_t red = sizeof(float) * 2 * NT * T * GMK_WG_RED_STRIDE;  // two parked partial tiles
   if (lds < red) lds = red;
   dim3 grid(g.G, g.csT * g.cbT * NTG);
 #define GMK_WG_LAUNCH(SB_, LGSW_)                                                                                  \

@@ -21,6 +21,7 @@ static size_t slab_bytes(const WgradGeom& g, int ksize) {
 
 static size_t wgrad_ws_bytes(int N, int Cs, int Cb, int SH, int SW, int ksize, int sb, int Cbias) {
   WgradGeom g{};
+  { static const int dbg = getenv("GMK_WG_DBG") ? atoi(getenv("GMK_WG_DBG")) : 0; g.dbg = dbg; }
   wgrad_plan(g, N, Cs, Cb, SH, SW, ksize, sb);
   (void)Cbias;
   return slab_bytes(g, ksize) + 256;
@@ -48,6 +49,7 @@ static int wgrad_run(const float* small, const float* big, float* dw, float* dbi
   if (!gmk_wgrad_supported(SH, SW, ksize, sb)) return GMK_E_SHAPE;  // square-ish power-of-two images, 8 <= width <= 64
   if (!gmk_aligned16(ws) || !gmk_aligned16(small) || !gmk_aligned16(big)) return GMK_E_ALIGN;
   WgradGeom g{};
+  { static const int dbg = getenv("GMK_WG_DBG") ? atoi(getenv("GMK_WG_DBG")) : 0; g.dbg = dbg; }
   wgrad_plan(g, N, Cs, Cb, SH, SW, ksize, sb);
   if (ws_bytes < slab_bytes(g, ksize)) return GMK_E_WORKSPACE;
   g.s = small; g.b = big; g.slab = (float*)ws;
