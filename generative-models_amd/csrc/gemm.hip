@@ -96,6 +96,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 // Requires the contiguous extents to be multiples of 4 and 16-byte aligned bases (host checks); rows / K beyond the
 // problem are clamped for the load and zeroed on the way into LDS, so the loop is branch-free.
 #define GLD 68  // LDS row stride (floats) of a [GK][64] tile: 16-byte rows for ds_write_b128
+// a_kfast / b_kfast: the operand is contiguous along k.  (A variant that issued ALL loads of a block's 128 / 256 deep K
+// range up front was measured and dropped: 128+ VGPRs halve the blocks per CU and the dgrad shapes got 30-50 % slower.)
+template <bool a_kfast, bool b_kfast>
 __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[2][2][GK * GLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -104,7 +107,8 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const GemmArgs g) {
   const int i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
   const int kbeg = blockIdx.z * g.kper;
   const int kend = min(g.K, kbeg + g.kper);
-  const bool a_kfast = (g.sak == 1), b_kfast = (g.sbk == 1);
+  // a_kfast / b_kfast (operand contiguous along k) are template parameters: as runtime flags they put every load under
+  // a branch, and the compiler then waits for vmcnt(0) after each one
   // per-thread quads: k-fast operand -> 8 quads per row (row = t/8 + 32u); row-fast operand -> 16 quads per k (k = t/16 + 16u)
   const float* abase[2]; const float* bbase[2];
   int a_k[2], b_k[2];      // first k (within the chunk) of the quad
@@ -139,18 +143,22 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const GemmArgs g) {
       b_k[u] = k; b_l[u] = k * GLD + q * 4;
     }
   }
-  float4 ar[2], br[2];
+  float4 arr[1][2], brr[1][2];
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto load_chunk = [&](int k0) {
+  auto load_chunk_to = [&](int k0, float4* ar, float4* br) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       int ka = k0 + a_k[u]; ka = ka < kend ? ka : kend - 4;  // clamped (kend % 4 == 0 for k-fast operands)
-      ar[u] = a_kfast ? *(const float4*)(abase[u] + ka) : *(const float4*)(abase[u] + (long long)min(k0 + a_k[u], kend - 1) * g.sak);
+      // one unconditional load per operand (the address is selected, not the load: loads under a branch make the
+      // compiler wait for vmcnt(0) at every join)
+      const float* pa = abase[u] + (a_kfast ? (long long)ka : (long long)min(k0 + a_k[u], kend - 1) * g.sak);
+      ar[u] = *(const float4*)pa;
       int kb = k0 + b_k[u]; kb = kb < kend ? kb : kend - 4;
-      br[u] = b_kfast ? *(const float4*)(bbase[u] + kb) : *(const float4*)(bbase[u] + (long long)min(k0 + b_k[u], kend - 1) * g.sbk);
+      const float* pb = bbase[u] + (b_kfast ? (long long)kb : (long long)min(k0 + b_k[u], kend - 1) * g.sbk);
+      br[u] = *(const float4*)pb;
     }
   };
-  auto store_chunk = [&](int k0, int buf) {
+  auto store_chunk_from = [&](int k0, int buf, const float4* ar, const float4* br) {
     float* As = smem[buf][0];
     float* Bs = smem[buf][1];
 #pragma unroll
@@ -166,13 +174,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const GemmArgs g) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  load_chunk(kbeg);
-  store_chunk(kbeg, 0);
-  int buf = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += GK, buf ^= 1) {
-    const bool more = k0 + GK < kend;  // uniform
-    if (more) load_chunk(k0 + GK);
-    gmk_lds_barrier();  // tile `buf` is complete; the other tile's readers (previous iteration) are done
+  auto mfma_chunk = [&](int buf) {
     const float* As = smem[buf][0];
     const float* Bs = smem[buf][1];
 #pragma unroll
@@ -181,7 +183,18 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const GemmArgs g) {
       const float b = Bs[(2 * s + h) * GLD + wc * 32 + l31];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
-    if (more) store_chunk(k0 + GK, buf ^ 1);
+  };
+  {
+    load_chunk_to(kbeg, arr[0], brr[0]);
+    store_chunk_from(kbeg, 0, arr[0], brr[0]);
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += GK, buf ^= 1) {
+      const bool more = k0 + GK < kend;  // uniform
+      if (more) load_chunk_to(k0 + GK, arr[0], brr[0]);
+      gmk_lds_barrier();  // tile `buf` is complete; the other tile's readers (previous iteration) are done
+      mfma_chunk(buf);
+      if (more) store_chunk_from(k0 + GK, buf ^ 1, arr[0], brr[0]);
+    }
   }
   const int j = j0 + wc * 32 + l31;
   if (j >= g.N) return;
@@ -196,11 +209,16 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const GemmArgs g) {
   // direct epilogue: the per-element factors (act' of dgrad) are all fetched before the math, the bias once per lane
   float mulv[16];
   const float bv = (g.epi == GEPI_BIAS_ACT && g.bias) ? g.bias[j] : 0.f;
+  if (g.epi == GEPI_MUL && g.mul) {  // one uniform branch around the whole batch of loads
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int i = i0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    const int ic = i < g.M ? i : g.M - 1;
-    mulv[r] = (g.epi == GEPI_MUL && g.mul) ? g.mul[(size_t)ic * g.ldc + j] : 1.f;
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int ic = i < g.M ? i : g.M - 1;
+      mulv[r] = g.mul[(size_t)ic * g.ldc + j];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mulv[r] = 1.f;
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -277,9 +295,12 @@ static int run_gemm(GemmArgs g, void* ws, size_t ws_bytes, hipStream_t s) {
   const bool a_k = g.sak == 1, b_k = g.sbk == 1;
   const bool a_fast = a_k ? (g.K % 4 == 0 && g.sai % 4 == 0) : (g.sai == 1 && g.M % 4 == 0 && g.sak % 4 == 0);
   const bool b_fast = b_k ? (g.K % 4 == 0 && g.sbj % 4 == 0) : (g.sbj == 1 && g.N % 4 == 0 && g.sbk % 4 == 0);
-  if (a_fast && b_fast && gmk_aligned16(g.A) && gmk_aligned16(g.B) && g.K >= 4)
-    hipLaunchKernelGGL(gemm_f32_pipe_kernel, grid, dim3(256), 0, s, g);
-  else
+  if (a_fast && b_fast && gmk_aligned16(g.A) && gmk_aligned16(g.B) && g.K >= 4) {
+    if (a_k && b_k) hipLaunchKernelGGL((gemm_f32_pipe_kernel<true, true>), grid, dim3(256), 0, s, g);
+    else if (a_k) hipLaunchKernelGGL((gemm_f32_pipe_kernel<true, false>), grid, dim3(256), 0, s, g);
+    else if (b_k) hipLaunchKernelGGL((gemm_f32_pipe_kernel<false, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_pipe_kernel<false, false>), grid, dim3(256), 0, s, g);
+  } else
     hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, g);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
