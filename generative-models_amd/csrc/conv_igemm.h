@@ -363,11 +363,17 @@ template <int KS>
 static int gmk_launch_conv_impl(ConvGeom& g, int mode, hipStream_t s) {
   constexpr int KK = KS * KS, PAD = (KS - 1) / 2;
   const int BH = (1 << g.lgBHW) / g.BW;
-  // tile choice: 64 out-channels x 128 base positions when that still gives >= 2 blocks per CU,
-  // else 64 x 64; 32 x 128 when the op has <= 32 output channels (dec.conv3: 3).
+  // tile choice (measured per mode at B = 256, tools/kbench.py under rocprofv3):
+  //   MODE 0/1, >= 512 tiles of 128 positions: 128 positions x 64 channels (WM 1, MT 2): two MFMAs per patch read
+  //   MODE 1 small, everything with <= 32 output channels ... : 64 x 64 (WM 2, MT 1) resp. 128 x 32 (WM 1, MT 1)
+  //   MODE 0 small: 128 x 32 (1 us faster than 64 x 64 on the 8x8 layers)
+  //   MODE 2: 128 positions x 32 channels (WM 1, MT 1): its four parity accumulators rule out MT 2 (spills), and
+  //   against 64 x 64 the weight slice staged per chunk halves: 89 -> 65 us for the 16->32 transposed conv.
   int WM, MT;
   if (g.M <= 32) { WM = 1; MT = 1; }
-  else if (mode != 2 && g.total_base / 128 >= 512) { WM = 1; MT = 2; }  // MODE2 keeps 4 parity accumulators (8 spill)
+  else if (mode == 2) { WM = 1; MT = 1; }
+  else if (g.total_base / 128 >= 512) { WM = 1; MT = 2; }
+  else if (mode == 0) { WM = 1; MT = 1; }
   else { WM = 2; MT = 1; }
   const int WP = 4 / WM, PT = WP * 32, MB = WM * MT * 32;
   if (g.BW > PT) return GMK_E_SHAPE;
