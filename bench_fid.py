@@ -18,6 +18,8 @@ def fid_stats_leg(device, rank, world, n_per_set=N_PER_SET, reps=3):
     ae = Autoencoder(variational=False, latent_size=256, num_channels=64, kernel_size=3,
                      act=get_activation_function("gelu"), sigmoid=True, interpolation="nearest",
                      no_pool=True, no_upsample=True, device=device).to(device)
+    with torch.no_grad():   # spread the random-init features out (as the fid_ae_e2e golden does) so that the two
+        ae.encoder.fc.weight.mul_(40.0)   # sets do not collapse onto one point and the reported FID is not ~0
     if world > 1:
         for p in ae.parameters():
             dist.broadcast(p.data, src=0)
@@ -27,7 +29,7 @@ def fid_stats_leg(device, rank, world, n_per_set=N_PER_SET, reps=3):
     fake = torch.rand(local, 3, 32, 32, device=device, generator=gen) ** 2   # a second distribution on [0,1)
 
     def run():
-        return metrics.compute_fid(model=ae, images1=real, images2=fake, batch_size=2048)
+        return metrics.compute_fid(model=ae, images1=real, images2=fake, batch_size=2048, sharded=True)
 
     run()
     torch.cuda.synchronize()

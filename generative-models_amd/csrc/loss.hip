@@ -7,9 +7,11 @@
 #define LOSS_BLOCKS 1024
 #define LOSS_THREADS 256
 
-extern "C" size_t gmk_vae_loss_workspace_bytes(void) { return sizeof(double) * 2 * LOSS_BLOCKS; }
+extern "C" size_t gmk_vae_loss_workspace_bytes(void) { return sizeof(double) * 4 * LOSS_BLOCKS; }
 
-template <bool SIGMOID, bool WRITE_RECON>
+// GRAD = false is the no-grad form of compute_test_loss (main.py:73-111): no gradient stores, and two more sums
+// (|mu| and sigma = exp(log_var / 2), main.py:101-102) ride along with the KL pass.
+template <bool SIGMOID, bool WRITE_RECON, bool GRAD>
 __global__ __launch_bounds__(LOSS_THREADS) void vae_loss_kernel(
     const float4* __restrict__ pre, const float4* __restrict__ image, const float2* __restrict__ stats,
     float4* __restrict__ recon_out, float4* __restrict__ dpre, float2* __restrict__ dstats,
@@ -27,14 +29,16 @@ __global__ __launch_bounds__(LOSS_THREADS) void vae_loss_kernel(
     }
     float dx = r.x - x.x, dy = r.y - x.y, dz = r.z - x.z, dw = r.w - x.w;
     se += dx * dx + dy * dy + dz * dz + dw * dw;
-    g.x = gscale * dx; g.y = gscale * dy; g.z = gscale * dz; g.w = gscale * dw;
-    if (SIGMOID) {
-      g.x *= r.x * (1.f - r.x); g.y *= r.y * (1.f - r.y); g.z *= r.z * (1.f - r.z); g.w *= r.w * (1.f - r.w);
+    if (GRAD) {
+      g.x = gscale * dx; g.y = gscale * dy; g.z = gscale * dz; g.w = gscale * dw;
+      if (SIGMOID) {
+        g.x *= r.x * (1.f - r.x); g.y *= r.y * (1.f - r.y); g.z *= r.z * (1.f - r.z); g.w *= r.w * (1.f - r.w);
+      }
+      dpre[i] = g;
     }
-    dpre[i] = g;
     if (WRITE_RECON) recon_out[i] = r;
   }
-  float kl = 0.f;
+  float kl = 0.f, amu = 0.f, sig = 0.f;
   for (int64_t i = gtid; i < nstat; i += gstride) {
     float2 s = stats[i];  // (mu, log_var)
     float2 g;
@@ -43,35 +47,48 @@ __global__ __launch_bounds__(LOSS_THREADS) void vae_loss_kernel(
       kl += s.x * s.x + (sg - 1.f) * (sg - 1.f);
       g.x = kscale * 2.f * s.x;
       g.y = kscale * (sg - 1.f) * sg;
+      if (!GRAD) sig += sg;
     } else {  // main.py:45
       float e = expf(s.y);
       kl += -0.5f * (1.f + s.y - s.x * s.x - e);
       g.x = kscale * s.x;
       g.y = kscale * 0.5f * (e - 1.f);
+      if (!GRAD) sig += expf(0.5f * s.y);
     }
-    dstats[i] = g;
+    if (GRAD) dstats[i] = g;
+    else amu += fabsf(s.x);
   }
-  __shared__ double red[2][LOSS_THREADS / 64];
+  __shared__ double red[4][LOSS_THREADS / 64];
   double a = gmk_wave_sum((double)se), b = gmk_wave_sum((double)kl);
+  double c = 0, d = 0;
+  if (!GRAD) { c = gmk_wave_sum((double)amu); d = gmk_wave_sum((double)sig); }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { red[0][wave] = a; red[1][wave] = b; }
+  if (lane == 0) { red[0][wave] = a; red[1][wave] = b; red[2][wave] = c; red[3][wave] = d; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double sa = 0, sb = 0;
-    for (int w = 0; w < LOSS_THREADS / 64; ++w) { sa += red[0][w]; sb += red[1][w]; }
+    double sa = 0, sb = 0, sc = 0, sd = 0;
+    for (int w = 0; w < LOSS_THREADS / 64; ++w) { sa += red[0][w]; sb += red[1][w]; sc += red[2][w]; sd += red[3][w]; }
     partial[blockIdx.x] = sa;
     partial[LOSS_BLOCKS + blockIdx.x] = sb;
+    if (!GRAD) { partial[2 * LOSS_BLOCKS + blockIdx.x] = sc; partial[3 * LOSS_BLOCKS + blockIdx.x] = sd; }
   }
 }
 
+// inv_bl > 0 selects the eval form: losses[3] = mean |mu|, losses[4] = mean sigma (over B*L elements)
 __global__ __launch_bounds__(256) void vae_loss_finalize_kernel(const double* __restrict__ partial, int nblocks,
                                                                 float* __restrict__ losses, double inv_n,
-                                                                double inv_b, float beta, int variational) {
-  __shared__ double red[2][4];
-  double a = 0, b = 0;
-  for (int i = threadIdx.x; i < nblocks; i += 256) { a += partial[i]; b += partial[LOSS_BLOCKS + i]; }
-  a = gmk_wave_sum(a); b = gmk_wave_sum(b);
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+                                                                double inv_b, float beta, int variational,
+                                                                double inv_bl) {
+  __shared__ double red[4][4];
+  double a = 0, b = 0, c = 0, d = 0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) {
+    a += partial[i]; b += partial[LOSS_BLOCKS + i];
+    if (inv_bl > 0) { c += partial[2 * LOSS_BLOCKS + i]; d += partial[3 * LOSS_BLOCKS + i]; }
+  }
+  a = gmk_wave_sum(a); b = gmk_wave_sum(b); c = gmk_wave_sum(c); d = gmk_wave_sum(d);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; red[2][threadIdx.x >> 6] = c; red[3][threadIdx.x >> 6] = d;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     double sa = red[0][0] + red[0][1] + red[0][2] + red[0][3];
@@ -81,18 +98,24 @@ __global__ __launch_bounds__(256) void vae_loss_finalize_kernel(const double* __
     losses[0] = rec;
     losses[1] = kl;
     losses[2] = variational ? rec + beta * kl : rec;
+    if (inv_bl > 0) {
+      losses[3] = variational ? (float)((red[2][0] + red[2][1] + red[2][2] + red[2][3]) * inv_bl) : 0.f;
+      losses[4] = variational ? (float)((red[3][0] + red[3][1] + red[3][2] + red[3][3]) * inv_bl) : 0.f;
+    }
   }
 }
 
-extern "C" int gmk_vae_loss_fwd_bwd(const float* pre, const float* image, const float* stats, float* recon_out,
-                                    float* dpre, float* dstats, float* losses, int64_t B, int64_t chw, int64_t L,
-                                    float beta, int flags, void* ws, size_t ws_bytes, gmk_stream_t stream) {
-  GMK_REQUIRE(pre && image && dpre && losses && ws, GMK_E_NULL);
+// shared by gmk_vae_loss_fwd_bwd (grad = true) and gmk_vae_loss_eval (grad = false; `losses` then has 5 floats)
+static int vae_loss_launch(const float* pre, const float* image, const float* stats, float* recon_out, float* dpre,
+                           float* dstats, float* losses, int64_t B, int64_t chw, int64_t L, float beta, int flags,
+                           void* ws, size_t ws_bytes, gmk_stream_t stream, bool grad) {
+  GMK_REQUIRE(pre && image && losses && ws, GMK_E_NULL);
+  GMK_REQUIRE(!grad || dpre, GMK_E_NULL);
   GMK_REQUIRE(B > 0 && chw > 0 && (B * chw) % 4 == 0, GMK_E_SHAPE);
   GMK_REQUIRE(ws_bytes >= gmk_vae_loss_workspace_bytes(), GMK_E_WORKSPACE);
   GMK_REQUIRE(gmk_aligned16(pre) && gmk_aligned16(image) && gmk_aligned16(dpre) && gmk_aligned16(ws), GMK_E_ALIGN);
   const bool variational = stats != nullptr;
-  if (variational) GMK_REQUIRE(dstats && L > 0, GMK_E_NULL);
+  if (variational) GMK_REQUIRE((dstats || !grad) && L > 0, GMK_E_NULL);
   if (recon_out) GMK_REQUIRE(gmk_aligned16(recon_out), GMK_E_ALIGN);
   hipStream_t s = (hipStream_t)stream;
   const int64_t n4 = B * chw / 4, nstat = variational ? B * L : 0;
@@ -103,18 +126,38 @@ extern "C" int gmk_vae_loss_fwd_bwd(const float* pre, const float* image, const 
   double* partial = (double*)ws;
   const bool sig = flags & GMK_LOSS_SIGMOID;
   const int msep = (flags & GMK_LOSS_MSE_PRIOR) ? 1 : 0;
-#define LAUNCH(S, R)                                                                                         \
-  hipLaunchKernelGGL((vae_loss_kernel<S, R>), dim3(nblocks), dim3(LOSS_THREADS), 0, s, (const float4*)pre,   \
+#define LAUNCH(S, R, G)                                                                                      \
+  hipLaunchKernelGGL((vae_loss_kernel<S, R, G>), dim3(nblocks), dim3(LOSS_THREADS), 0, s, (const float4*)pre, \
                      (const float4*)image, (const float2*)stats, (float4*)recon_out, (float4*)dpre,          \
                      (float2*)dstats, partial, n4, nstat, gscale, kscale, msep)
-  if (sig) { if (recon_out) LAUNCH(true, true); else LAUNCH(true, false); }
-  else     { if (recon_out) LAUNCH(false, true); else LAUNCH(false, false); }
+  if (grad) {
+    if (sig) { if (recon_out) LAUNCH(true, true, true); else LAUNCH(true, false, true); }
+    else     { if (recon_out) LAUNCH(false, true, true); else LAUNCH(false, false, true); }
+  } else {
+    if (sig) { if (recon_out) LAUNCH(true, true, false); else LAUNCH(true, false, false); }
+    else     { if (recon_out) LAUNCH(false, true, false); else LAUNCH(false, false, false); }
+  }
 #undef LAUNCH
   GMK_CHECK_LAUNCH();
   hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, s, partial, nblocks, losses,
-                     1.0 / ((double)B * (double)chw), 1.0 / (double)B, beta, variational ? 1 : 0);
+                     1.0 / ((double)B * (double)chw), 1.0 / (double)B, beta, variational ? 1 : 0,
+                     grad ? 0.0 : 1.0 / ((double)B * (double)(L > 0 ? L : 1)));
   GMK_CHECK_LAUNCH();
   return GMK_OK;
+}
+
+extern "C" int gmk_vae_loss_fwd_bwd(const float* pre, const float* image, const float* stats, float* recon_out,
+                                    float* dpre, float* dstats, float* losses, int64_t B, int64_t chw, int64_t L,
+                                    float beta, int flags, void* ws, size_t ws_bytes, gmk_stream_t stream) {
+  return vae_loss_launch(pre, image, stats, recon_out, dpre, dstats, losses, B, chw, L, beta, flags, ws, ws_bytes,
+                         stream, true);
+}
+
+extern "C" int gmk_vae_loss_eval(const float* pre, const float* image, const float* stats, float* recon_out,
+                                 float* out5, int64_t B, int64_t chw, int64_t L, float beta, int flags, void* ws,
+                                 size_t ws_bytes, gmk_stream_t stream) {
+  return vae_loss_launch(pre, image, stats, recon_out, nullptr, nullptr, out5, B, chw, L, beta, flags, ws, ws_bytes,
+                         stream, false);
 }
 
 // ---- reparameterisation ---------------------------------------------------------------

@@ -87,6 +87,8 @@ def get_cifar(dataset='cifar', data_dir='data', train_batch_size=50, test_batch_
               device=None, rank=0, world=1, seed=0):
     """device = a CUDA device -> GPU-resident loaders (GpuCifarLoader); None / CPU -> torch DataLoaders over CPU tensors
     (what the reference returns, dataloaders.py:37-43)."""
+    if str(dataset).lower() not in ('cifar', 'cifar10'):
+        raise NotImplementedError(f'dataset {dataset!r}: only CIFAR-10 is on the path (the reference\'s MNIST branch is unused)')
     root = os.path.join(data_dir, 'cifar-10-batches-py')
     if os.path.isdir(root):
         xtr, ytr = _load_cifar_batches(root, [f'data_batch_{i}' for i in range(1, 6)])
@@ -100,8 +102,8 @@ def get_cifar(dataset='cifar', data_dir='data', train_batch_size=50, test_batch_
         yte = torch.randint(0, 10, (synthetic_size[1],), generator=g)
     if device is not None and torch.device(device).type == 'cuda':
         return (GpuCifarLoader(xtr, ytr, train_batch_size, True, device, rank, world, seed),
-                GpuCifarLoader(xte, yte, test_batch_size, False, device, 0, 1, seed))
+                GpuCifarLoader(xte, yte, test_batch_size, False, device, 0, 1, seed, shuffle=False))  # dataloaders.py:41
     xtr, xte = xtr.float().div_(255.0), xte.float().div_(255.0)
     train_dataloader = DataLoader(_Images(xtr, ytr, True), batch_size=train_batch_size, shuffle=True)
-    test_dataloader = DataLoader(_Images(xte, yte, False), batch_size=test_batch_size, shuffle=True)
+    test_dataloader = DataLoader(_Images(xte, yte, False), batch_size=test_batch_size, shuffle=False)  # dataloaders.py:41
     return train_dataloader, test_dataloader

@@ -61,8 +61,9 @@ def encoder_forward(p, x, *, act, no_pool, ksize, train):
     return out, sv
 
 
-def encoder_backward(p, sv, dout, *, no_pool, ksize, gout=None, on_fc_done=None, side=None):
-    """dout: (B, mult*L) gradient of the encoder output.  Returns param grads."""
+def encoder_backward(p, sv, dout, *, no_pool, ksize, gout=None, on_fc_done=None, side=None, need_dx=False):
+    """dout: (B, mult*L) gradient of the encoder output.  Returns param grads (+ "__dx__", the gradient w.r.t. the
+    input image, when need_dx)."""
     g = {}
     B = dout.shape[0]
     x = sv["x"]
@@ -88,6 +89,8 @@ def encoder_backward(p, sv, dout, *, no_pool, ksize, gout=None, on_fc_done=None,
         da2 = ops.conv2d_dgrad(dz3, p["conv2.weight"], tuple(sv["a2"].shape), 1)
         dz1 = ops.maxpool2_bwd(da2, sv["i1"], dact_in=sv["d1"])
     g["conv1.weight"], g["conv1.bias"] = _wg(side, lambda: ops.conv2d_wgrad(dz1, x, ksize, 1, out=_o(gout, "conv1")), dz1)
+    if need_dx:
+        g["__dx__"] = ops.conv2d_dgrad(dz1, p["conv1.weight"], tuple(x.shape), 1)
     return g
 
 

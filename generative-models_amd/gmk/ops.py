@@ -229,6 +229,21 @@ def vae_loss_fwd_bwd(pre, image, stats, beta, sigmoid=True, mse_prior=False, wan
     return losses, dpre, dstats, recon
 
 
+def vae_loss_eval(pre, image, stats, beta, sigmoid=True, mse_prior=False, want_recon=False):
+    """No-grad form (compute_test_loss, main.py:73-111): returns (out5 = rec, kl, total, mean|mu|, mean sigma ; recon or None)."""
+    _chk(pre, image, stats)
+    B = pre.shape[0]
+    chw = pre.numel() // B
+    L = 0 if stats is None else stats.shape[1]
+    recon = torch.empty_like(pre) if want_recon else None
+    out5 = torch.empty(5, device=pre.device, dtype=torch.float32)
+    ws = workspace(lib().gmk_vae_loss_workspace_bytes(), pre.device)
+    flags = (LOSS_SIGMOID if sigmoid else 0) | (LOSS_MSE_PRIOR if mse_prior else 0)
+    check(lib().gmk_vae_loss_eval(_p(pre), _p(image), _p(stats), _p(recon), _p(out5), B, chw, L, float(beta), flags,
+                                  _p(ws), ws.numel(), _stream()))
+    return out5, recon
+
+
 def maxpool2_fwd(x, want_idx=True):
     _chk(x)
     N, C, H, W = x.shape

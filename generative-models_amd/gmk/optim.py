@@ -13,7 +13,18 @@ from ._lib import lib, check
 
 class FusedAdamW(torch.optim.AdamW):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, **kw):
-        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **kw)
+        # the kernel implements plain AdamW (what the reference constructs, main.py:214); options that change the
+        # update rule are refused instead of being silently ignored
+        for flag in ("amsgrad", "maximize", "capturable", "differentiable"):
+            if kw.pop(flag, False):
+                raise NotImplementedError(f"FusedAdamW: {flag}=True is not implemented by gmk_adamw_step")
+        for flag in ("foreach", "fused"):   # implementation selectors of torch's own step(): meaningless here
+            kw.pop(flag, None)
+        if kw:
+            raise TypeError(f"FusedAdamW: unexpected arguments {sorted(kw)}")
+        if isinstance(lr, torch.Tensor):
+            raise NotImplementedError("FusedAdamW: a tensor lr is not supported (the kernel takes a host scalar)")
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         if len(self.param_groups) != 1:
             raise NotImplementedError("FusedAdamW supports a single param group (the reference uses one)")
         self.grad_scale = 1.0  # set to 1/world_size by the DP reducer (SUM all-reduce)

@@ -47,6 +47,10 @@ def train_one_epoch(args, model, epoch=None, beta=None, train_dataloader=None, o
             writer.add_scalar('Train Loss/Total', tot, i)
             writer.add_scalar('Train Loss/beta', beta, i)
         count += 1
+    if reducer is not None and reducer.world > 1:
+        # every rank saw its own shard: report the mean over ranks (one 3-float all-reduce per epoch)
+        torch.distributed.all_reduce(total, group=reducer.group)
+        total /= reducer.world
     avg_train_rec_loss = total[0] / len(train_dataloader)
     avg_train_kl_loss = beta * total[1] / len(train_dataloader) if args.variational else 0
     if args.variational:  # to combat vanishing KL loss
@@ -55,29 +59,25 @@ def train_one_epoch(args, model, epoch=None, beta=None, train_dataloader=None, o
 
 
 def compute_test_loss(args, model, beta=None, test_dataloader=None, device=None):
-    """main.py:73-111: eval-mode losses plus mean |mu| and mean sigma of the latent."""
-    import torch.nn.functional as F
+    """main.py:73-111: eval-mode losses plus mean |mu| and mean sigma of the latent.  Each batch is one no-grad
+    forward + the fused loss kernel in its eval form (gmk_vae_loss_eval); the per-batch values are accumulated
+    on the device, so the loop never synchronises."""
     model.eval()
     n = len(test_dataloader)
-    acc = torch.zeros(4, device=device)   # rec, kl, mean |mu|, mean sigma
-    with torch.no_grad():
-        for test_image, _ in test_dataloader:
-            test_image = test_image.to(device)
-            acc[0] += F.mse_loss(model(test_image), test_image)
-            if not args.variational:
-                continue
-            mu, log_var = model.stats[:, :, 0], model.stats[:, :, 1]
-            sigma = torch.exp(0.5 * log_var)
-            if args.mse:
-                acc[1] += (mu ** 2).sum(1).mean(0) + ((sigma - 1) ** 2).sum(1).mean(0)
-            else:
-                acc[1] += (-0.5 * (1 + log_var - mu ** 2 - log_var.exp()).sum(dim=1)).mean(dim=0)
-            acc[2] += mu.abs().mean()
-            acc[3] += sigma.abs().mean()
-    rec, kl, latent_mean, latent_std = (acc / n).unbind()
+    acc = torch.zeros(5, device=device)   # rec, kl, rec + beta*kl, mean |mu|, mean sigma
+    for test_image, _ in test_dataloader:
+        acc += model.eval_losses(test_image.to(device), beta=beta if args.variational else 0.0, mse_prior=args.mse)
+    rec, kl, _, latent_mean, latent_std = (acc / n).unbind()
     if not args.variational:
         kl = latent_mean = latent_std = 0
     return latent_mean, latent_std, rec, beta * kl
+
+
+def make_checkpoint(model, optim, lr_scheduler, epoch, args, beta, loss_str):
+    """The resume dict of /root/reference/main.py:323-331: same keys, same value types (torch.optim.AdamW /
+    CosineAnnealingLR state_dict layouts, the completed epoch, the grown beta, the printed loss string)."""
+    return dict(state_dict=model.state_dict(), optimizer=optim.state_dict(), lr_scheduler=lr_scheduler.state_dict(),
+                epoch=epoch, args=args, current_beta=beta, losses=loss_str)
 
 
 def compute_metrics(autoencoder=None, classifier=None, real_images=None, samples=None, debug=False):
@@ -207,6 +207,20 @@ def main(args):
                     autoencoder=plain_ae, classifier=classifier, real_images=test_input_images.to(device),
                     samples=samples, debug=True)
                 metrics_str = f'  FID (classifier/AE): {fid_classifier:.1f}/{fid_ae:.1f}  confidence {confidence:.1f}  diversity {diversity:.1f}  IS {inception_score:.2f}'
+            if writer is not None and rank == 0:   # reference main.py:299-311 (it raises NameError without --variational)
+                i = epoch * len(train_dataloader)
+                writer.add_scalar('Test Loss/KL', float(avg_test_kl_loss), i)
+                writer.add_scalar('Test Loss/Reconstruction', float(avg_test_rec_loss), i)
+                writer.add_scalar('Test Loss/Total', float(avg_test_rec_loss) + float(avg_test_kl_loss), i)
+                writer.add_scalar('Test Loss/beta', beta, i)
+                writer.add_scalar('Latent Vector/mean', float(avg_latent_mean), i)
+                writer.add_scalar('Latent Vector/std', float(avg_latent_std), i)
+                if args.variational:
+                    writer.add_scalar('FID/classifier', float(fid_classifier), i)
+                    writer.add_scalar('FID/plain_ae', float(fid_ae), i)
+                    writer.add_scalar('Metrics/confidence', float(confidence), i)
+                    writer.add_scalar('Metrics/diversity', float(diversity), i)
+                    writer.add_scalar('Metrics/inception score', float(inception_score), i)
             latent_stats_str = f'  mean {avg_latent_mean:.4f} std {avg_latent_std:.4f}' if args.variational else ''
             kl_loss_str = f'  kl train {1000*avg_train_kl_loss:.2f} test {1000*avg_test_kl_loss:.2f}' if args.variational else ''
             loss_str = f'losses:  train {1000*avg_train_rec_loss:.2f} test {1000*avg_test_rec_loss:.2f}{kl_loss_str}'
@@ -216,9 +230,7 @@ def main(args):
                 print(f'{time_str}  Epoch {epoch:>3d}   {loss_str}{latent_stats_str}{metrics_str}{changes_str}')
                 plot_grid(model, train_input_images[:4], name=experiment_str + '_train')
                 plot_grid(model, test_input_images[:4], name=experiment_str + '_test')
-                checkpoint = dict(state_dict=model.state_dict(), optimizer=optim.state_dict(),
-                                  lr_scheduler=lr_scheduler.state_dict(), epoch=epoch, args=args,
-                                  current_beta=beta, losses=loss_str)   # keys of reference main.py:219-226
+                checkpoint = make_checkpoint(model, optim, lr_scheduler, epoch, args, beta, loss_str)
                 torch.save(checkpoint, 'checkpoints/' + experiment_str + ".pth")
                 model.sample(name=experiment_str)
         if rank == 0 and not os.path.isfile(args.ae_checkpoint):  # save full model checkpoint

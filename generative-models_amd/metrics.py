@@ -6,8 +6,9 @@ What changes underneath (results are held to the reference: 0.05 absolute on FID
     the GPU; for our Autoencoder only the encoder half runs (the decoder output is discarded by the
     reference as well, metrics.py:70-73);
   * mean / covariance come from fp64 moments (n, sum x, sum x x^T) accumulated by an MFMA kernel;
-    under torch.distributed each rank passes ITS shard of the images and the moments are combined
-    with ONE all-reduce (SURVEY 8e);
+    with sharded=True under torch.distributed each rank passes ITS shard of the images and the moments
+    are combined with ONE all-reduce; the default (sharded=False) is the reference's call
+    shape -- every caller holds the whole set -- and runs no collective;
   * tr sqrt(S1 S2) comes from two symmetric Newton-Schulz square roots on the device instead of
     scipy's Schur sqrtm; there is no complex arithmetic, so the reference's imaginary-component
     ValueError (metrics.py:100-104) cannot occur; its non-finite -> "+eps on the diagonal" retry
@@ -36,8 +37,10 @@ def _features(model, images, batch_size):
             yield model.latent_vector.detach().float().contiguous()
 
 
-def feature_moments(model, images, batch_size=1024, group=None):
-    """(n, s (D) f64, G (D,D) f64) of model.latent_vector over `images`, all-reduced over `group`."""
+def feature_moments(model, images, batch_size=1024, group=None, sharded=False):
+    """(n, s (D) f64, G (D,D) f64) of model.latent_vector over `images`.  sharded=True: `images` is THIS rank's
+    shard of the sample set and the moments are combined with one all-reduce over `group`; sharded=False (the
+    reference's call shape, every rank holding the same images): no collective."""
     model.eval()
     s = G = None
     n = 0
@@ -50,7 +53,7 @@ def feature_moments(model, images, batch_size=1024, group=None):
             ops.gram_accumulate(f, G, s)
             n += f.shape[0]
     packed[0] = n
-    if _world(group) > 1:
+    if sharded and _world(group) > 1:
         dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)  # the ONE exchange step of the FID path
     return int(round(packed[0].item())), s, G
 
@@ -65,17 +68,18 @@ def fid_from_moments(m1, m2, eps=1e-6, iters=50, delta=1e-12):
     return np.float64(fid)
 
 
-def compute_fid(model=None, images1=None, images2=None, eps=1e-6, batch_size=1024, group=None):
-    """Frechet distance between the latent features of two image sets (metrics.py:37-108)."""
+def compute_fid(model=None, images1=None, images2=None, eps=1e-6, batch_size=1024, group=None, sharded=False):
+    """Frechet distance between the latent features of two image sets (metrics.py:37-108).
+    sharded=True: every rank passes its own shard of both sets (see feature_moments)."""
     images1 = images1.to(images2.device)
     model = model.to(images2.device)
-    m1 = feature_moments(model, images1, batch_size, group)
-    m2 = feature_moments(model, images2, batch_size, group)
+    m1 = feature_moments(model, images1, batch_size, group, sharded)
+    m2 = feature_moments(model, images2, batch_size, group, sharded)
     assert m1[1].shape == m2[1].shape, 'Training and test mean vectors have different lengths'
     return fid_from_moments(m1, m2, eps=eps)
 
 
-def _logit_stats(classifier, images, N, eps, batch_size, group):
+def _logit_stats(classifier, images, N, eps, batch_size, group, sharded=False):
     device = images.device
     classifier = classifier.to(device)
     classifier.eval()
@@ -84,15 +88,16 @@ def _logit_stats(classifier, images, N, eps, batch_size, group):
         for i in range(0, images.shape[0], batch_size):
             logits = classifier(images[i:i + batch_size]).detach().float().contiguous()
             out = ops.softmax_stats(logits, out=out, topn=N, eps=eps)
-    if _world(group) > 1:
-        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+    if sharded and _world(group) > 1:
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)  # the one exchange of the IS / conf / div path
     C = (out.numel() - 4) // 2
     return out, C
 
 
-def compute_confidence_diversity(classifier, images, N=3, alpha=0.7, debug=False, batch_size=4096, group=None):
+def compute_confidence_diversity(classifier, images, N=3, alpha=0.7, debug=False, batch_size=4096, group=None,
+                                 sharded=False):
     """metrics.py:110-201: returns (100*confidence, 100*diversity) as torch scalars on images.device."""
-    st, C = _logit_stats(classifier, images, max(N, 1), 1e-7, batch_size, group)
+    st, C = _logit_stats(classifier, images, max(N, 1), 1e-7, batch_size, group, sharded)
     n = st[2 * C + 3]
     top1_ratio = (st[2 * C + 1] / n).float()
     if N > 1:
@@ -113,9 +118,9 @@ def compute_confidence_diversity(classifier, images, N=3, alpha=0.7, debug=False
     return 100 * confidence_score, 100 * diversity_score2
 
 
-def compute_inception_score(classifier, images, eps=1e-7, batch_size=4096, group=None):
+def compute_inception_score(classifier, images, eps=1e-7, batch_size=4096, group=None, sharded=False):
     """metrics.py:204-267: IS = exp(H(mean_n p) - mean_n H(p_n)), eps inside the logs."""
-    st, C = _logit_stats(classifier, images, 1, eps, batch_size, group)
+    st, C = _logit_stats(classifier, images, 1, eps, batch_size, group, sharded)
     n = st[2 * C + 3]
     confidence_entropy = (st[2 * C] / n).float()
     class_frequencies = (st[:C] / n).float()

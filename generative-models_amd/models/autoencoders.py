@@ -38,9 +38,10 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         mod = ctx.mod
-        g = engine.encoder_backward(ctx.p, ctx.sv, dout.contiguous(), no_pool=mod.no_pool, ksize=mod.kernel_size)
-        ctx.sv = None
-        return (None, None, None, None) + tuple(g[n] for n in ctx.names)
+        g = engine.encoder_backward(ctx.p, ctx.sv, dout.contiguous(), no_pool=mod.no_pool, ksize=mod.kernel_size,
+                                    need_dx=ctx.needs_input_grad[1])
+        dx = g.pop("__dx__", None)
+        return (None, dx, None, None) + tuple(g[n] for n in ctx.names)
 
 
 class _DecoderFn(torch.autograd.Function):
@@ -48,7 +49,7 @@ class _DecoderFn(torch.autograd.Function):
     def forward(ctx, mod, z, names, train, *params):
         p = dict(zip(names, params))
         out, sv = engine.decoder_forward(p, z.contiguous(), act=mod._act_id, num_channels=mod.num_channels,
-                                         no_upsample=mod.no_upsample, interpolation=mod.interpolation,
+                                         no_upsample=mod.no_upsample, interpolation=mod._interp,
                                          ksize=mod.kernel_size, base=mod.base, train=train,
                                          final_act="sigmoid" if mod.use_sigmoid else None)
         ctx.mod, ctx.names, ctx.p, ctx.sv = mod, names, p, sv
@@ -61,9 +62,8 @@ class _DecoderFn(torch.autograd.Function):
         if mod.use_sigmoid:
             dpre = ops.ew_mul(dpre, ctx.sv["e5"])
         g, dz = engine.decoder_backward(ctx.p, ctx.sv, dpre, no_upsample=mod.no_upsample,
-                                        interpolation=mod.interpolation, ksize=mod.kernel_size,
+                                        interpolation=mod._interp, ksize=mod.kernel_size,
                                         need_dz=ctx.needs_input_grad[1])
-        ctx.sv = None
         return (None, dz, None, None) + tuple(g[n] for n in ctx.names)
 
 
@@ -91,6 +91,11 @@ def _padding(kernel_size):
 
 
 class Encoder(nn.Module):
+    # A full-model pickle written by the reference (main.py:338-339, loaded at main.py:189-195) restores __dict__
+    # without running __init__: its Encoder has no `base` (8x8 is hard-coded there, autoencoders.py:41), so the
+    # class-level default stands in.
+    base = 8
+
     def __init__(self, variational=False, latent_size=None, num_channels=None, kernel_size=None, act=None,
                  no_pool=False, debug=False, base=8) -> None:
         super().__init__()
@@ -136,6 +141,16 @@ class Encoder(nn.Module):
 
 
 class Decoder(nn.Module):
+    base = 8   # see Encoder.base: reference pickles carry neither `base` nor `interpolation` (autoencoders.py:68-91)
+
+    @property
+    def _interp(self):
+        """Upsampling mode: our own attribute, or (reference-written pickle) the nn.Upsample child's mode."""
+        mode = self.__dict__.get("interpolation")
+        if mode is None and not self.no_upsample:
+            mode = self.upsample.mode
+        return mode or "nearest"
+
     def __init__(self, latent_size, num_channels=None, kernel_size=None, act=None, sigmoid=None,
                  interpolation='bilinear', no_upsample=False, debug=False, base=8) -> None:
         super().__init__()
@@ -239,6 +254,33 @@ class Autoencoder(nn.Module):
             self.latent_vector = out
         return self.latent_vector
 
+    @torch.no_grad()
+    def eval_losses(self, image, beta=0.0, mse_prior=False, eps=None):
+        """No-grad forward + the fused loss kernel in its eval form: what one iteration of the reference's
+        compute_test_loss evaluates (/root/reference/main.py:84-102).  Returns a device tensor
+        [rec, kl (unweighted), rec + beta*kl, mean |mu|, mean sigma]; sets .stats/.normal/.latent_vector like forward().
+        `eps` replaces the randn_like draw (the reference samples in eval mode as well, autoencoders.py:174)."""
+        enc, dec = self.encoder, self.decoder
+        pe = {n: p.data for n, p in enc.named_parameters()}
+        pd = {n: p.data for n, p in dec.named_parameters()}
+        image = image.contiguous()
+        B = image.shape[0]
+        out, _ = engine.encoder_forward(pe, image, act=enc._act_id, no_pool=enc.no_pool, ksize=enc.kernel_size, train=False)
+        if self.variational:
+            stats = out.view(B, self.latent_size, 2)
+            if eps is None:
+                eps = torch.randn((B, self.latent_size), device=image.device, dtype=torch.float32)
+            z = ops.reparam_fwd(stats, eps)
+            self.stats, self.normal = stats, eps
+        else:
+            stats, z = None, out
+        self.latent_vector = z
+        pre, _ = engine.decoder_forward(pd, z, act=dec._act_id, num_channels=dec.num_channels,
+                                        no_upsample=dec.no_upsample, interpolation=dec._interp,
+                                        ksize=dec.kernel_size, base=dec.base, train=False, final_act=None)
+        out5, _ = ops.vae_loss_eval(pre, image, stats, beta, sigmoid=bool(dec.use_sigmoid), mse_prior=mse_prior)
+        return out5
+
     # ------------------------------------------------------------------ fused train step
     def train_step(self, image, beta=0.0, mse_prior=False, eps=None, reducer=None):
         """Forward + fused loss + backward of /root/reference/main.py:29-51 without autograd.
@@ -249,10 +291,7 @@ class Autoencoder(nn.Module):
         `reducer` (gmk.parallel.GradReducer) is told as soon as each gradient bucket is enqueued so
         that its all-reduce overlaps the rest of backward.
         """
-        if not self.decoder.use_sigmoid:
-            sigmoid = False
-        else:
-            sigmoid = True
+        sigmoid = bool(self.decoder.use_sigmoid)
         enc, dec = self.encoder, self.decoder
         pe = {n: p.data for n, p in enc.named_parameters()}
         pd = {n: p.data for n, p in dec.named_parameters()}
@@ -274,7 +313,7 @@ class Autoencoder(nn.Module):
             stats, z = None, out
         self.latent_vector = z
         pre, svd = engine.decoder_forward(pd, z, act=dec._act_id, num_channels=dec.num_channels,
-                                          no_upsample=dec.no_upsample, interpolation=dec.interpolation,
+                                          no_upsample=dec.no_upsample, interpolation=dec._interp,
                                           ksize=dec.kernel_size, base=dec.base, train=True, final_act=None)
         losses, dpre, dstats, _ = ops.vae_loss_fwd_bwd(pre, image, stats, beta, sigmoid=sigmoid, mse_prior=mse_prior)
         # weight gradients run on a side stream, overlapping the dgrad chain on this one (gmk.ops.SideQueue)
@@ -289,7 +328,7 @@ class Autoencoder(nn.Module):
                 with torch.cuda.stream(side.stream):
                     reducer.ready(name)
 
-        _, dz = engine.decoder_backward(pd, svd, dpre, no_upsample=dec.no_upsample, interpolation=dec.interpolation,
+        _, dz = engine.decoder_backward(pd, svd, dpre, no_upsample=dec.no_upsample, interpolation=dec._interp,
                                         ksize=dec.kernel_size, need_dz=True, gout=gd, side=side)
         bucket_ready("decoder")
         if self.variational:

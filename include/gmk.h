@@ -130,6 +130,13 @@ int gmk_vae_loss_fwd_bwd(const float* pre, const float* image, const float* stat
                          float* recon_out, float* dpre, float* dstats, float* losses,
                          int64_t B, int64_t chw, int64_t L, float beta, int flags,
                          void* ws, size_t ws_bytes, gmk_stream_t stream);
+/* gmk_vae_loss_eval: the no-grad form of the same kernel, for the eval pass of
+ *   /root/reference/main.py:73-111 (compute_test_loss): no gradient stores; out5 = 5 floats on device
+ *   {rec, kl, total = rec + beta*kl, mean_{b,l} |mu| (main.py:101), mean_{b,l} exp(log_var/2) (main.py:102)};
+ *   the last two are 0 when stats == NULL.  recon_out may be NULL.  Same workspace as above. */
+int gmk_vae_loss_eval(const float* pre, const float* image, const float* stats, float* recon_out,
+                      float* out5, int64_t B, int64_t chw, int64_t L, float beta, int flags,
+                      void* ws, size_t ws_bytes, gmk_stream_t stream);
 
 /* ---------------------------------------------------------------- pool / upsample -------
  * Pool + upsample variants of the autoencoder (models/autoencoders.py:40,48,52,89,100,104).

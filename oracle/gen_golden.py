@@ -318,11 +318,213 @@ def gen_classifier():
         json.dump(out, f, indent=1)
 
 
+# ---------------------------------------------------------------------------------------------------
+# round 2: multi-step optimizer trajectory, eval-mode sampling, the epoch loop (train_one_epoch +
+# compute_test_loss), and reference-written checkpoint / full-model pickle fixtures
+class _Queue:
+    """Replaces torch.randn_like / torch.randn while the reference runs: returns the queued tensors in order."""
+    def __init__(self, items):
+        self.items = list(items)
+
+    def __call__(self, *a, **k):
+        return self.items.pop(0)
+
+
+def _with_patched(name, fn, body):
+    orig = getattr(torch, name)
+    setattr(torch, name, fn)
+    try:
+        return body()
+    finally:
+        setattr(torch, name, orig)
+
+
+def ref_train_one_epoch(args, model, beta, batches, eps_list, optim, lr_scheduler):
+    """/root/reference/main.py:21-70 restated around the imported model (main.py itself needs tensorboard and
+    torchvision datasets to import).  `batches` replaces the DataLoader, `eps_list` the randn_like draws."""
+    import torch.nn.functional as F
+    model.train()
+    total_train_rec_loss = 0
+    total_train_kl_loss = 0
+    q = _Queue(eps_list)
+    for image in batches:
+        reconstructed = _with_patched("randn_like", q, lambda: model(image))
+        train_rec_loss = F.mse_loss(reconstructed, image)
+        total_train_rec_loss += train_rec_loss
+        train_loss = train_rec_loss
+        if args.variational:
+            mu = model.stats[:, :, 0]
+            log_var = model.stats[:, :, 1]
+            sigma = torch.exp(0.5 * log_var)
+            if args.mse:
+                mu_loss = F.mse_loss(mu, torch.zeros_like(mu), reduction='none')
+                sigma_loss = F.mse_loss(sigma, torch.ones_like(sigma), reduction='none')
+                train_kl_loss = mu_loss.sum(1).mean(0) + sigma_loss.sum(1).mean(0)
+            else:
+                train_kl_loss = torch.mean(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=0)
+            total_train_kl_loss += beta * train_kl_loss
+            train_loss += beta * train_kl_loss
+        optim.zero_grad()
+        train_loss.backward()
+        optim.step()
+        lr_scheduler.step()
+    if args.variational:
+        beta *= args.beta_mult
+    return beta, total_train_rec_loss / len(batches), total_train_kl_loss / len(batches)
+
+
+def ref_compute_test_loss(args, model, beta, batches, eps_list):
+    """/root/reference/main.py:73-111 restated around the imported model."""
+    import torch.nn.functional as F
+    model.eval()
+    q = _Queue(eps_list)
+    with torch.no_grad():
+        total_test_rec_loss = 0
+        total_test_kl_loss = 0
+        latent_mean = 0
+        latent_std = 0
+        for test_image in batches:
+            test_reconstructed = _with_patched("randn_like", q, lambda: model(test_image))
+            total_test_rec_loss += F.mse_loss(test_reconstructed, test_image)
+            if args.variational:
+                mu = model.stats[:, :, 0]
+                log_var = model.stats[:, :, 1]
+                sigma = torch.exp(0.5 * log_var)
+                if args.mse:
+                    mu_loss = F.mse_loss(mu, torch.zeros_like(mu), reduction='none')
+                    sigma_loss = F.mse_loss(sigma, torch.ones_like(sigma), reduction='none')
+                    test_kl_loss = mu_loss.sum(1).mean(0) + sigma_loss.sum(1).mean(0)
+                else:
+                    test_kl_loss = torch.mean(-0.5 * torch.sum(1 + log_var - mu ** 2 - log_var.exp(), dim=1), dim=0)
+                total_test_kl_loss += test_kl_loss
+                latent_mean += mu.abs().mean()
+                latent_std += sigma.abs().mean()
+        n = len(batches)
+        return latent_mean / n, latent_std / n, total_test_rec_loss / n, beta * total_test_kl_loss / n
+
+
+def _epoch_inputs(tag, variational, L, nb_train, nb_test, B):
+    tr = [detgen.images(f"{tag}/train{i}", B) for i in range(nb_train)]
+    te = [detgen.images(f"{tag}/test{i}", B) for i in range(nb_test)]
+    etr = [detgen.normal(f"{tag}/eps_train{i}", (B, L)) for i in range(nb_train)] if variational else []
+    ete = [detgen.normal(f"{tag}/eps_test{i}", (B, L)) for i in range(nb_test)] if variational else []
+    return tr, te, etr, ete
+
+
+def gen_extra():
+    out = {}
+    T = torch.from_numpy
+
+    # (1) three consecutive reference steps, ONE AdamW + CosineAnnealingLR (lr moves a lot: T_max=5)
+    for name, variational in (("ae_cfg1_b8", False), ("vae_cfg2_b8", True)):
+        cfg = base_cfg(variational=variational)
+        shape_cfg = dict(variational=variational, latent_size=256, num_channels=64, kernel_size=3, no_pool=True, no_upsample=True)
+        params = detgen.ae_params(name, **shape_cfg)
+        model = build_ref(cfg, params, "gelu")
+        optim = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+        sched = torch.optim.lr_scheduler.CosineAnnealingLR(optim, T_max=5)
+        args = types.SimpleNamespace(variational=variational, mse=False, beta_mult=1.0)
+        steps = []
+        for i in range(3):
+            x = T(detgen.images(f"{name}/step{i}", 8))
+            eps = [T(detgen.normal(f"{name}/eps{i}", (8, 256)))] if variational else []
+            _, rec, kl = ref_train_one_epoch(args, model, 5e-6, [x], eps, optim, sched)
+            steps.append(dict(rec=float(rec), beta_kl=float(kl), lr_after=sched.get_last_lr()[0],
+                              param_norm={k: l2(p.detach()) for k, p in model.named_parameters()}))
+        st = optim.state_dict()["state"]
+        names = [k for k, _ in model.named_parameters()]
+        out[f"steps3_{name}"] = dict(
+            steps=steps, T_max=5, lr=1e-3, wd=0.01, beta=5e-6,
+            param_sample={k: sample(p.detach()) for k, p in model.named_parameters()},
+            exp_avg_norm={names[i]: l2(s["exp_avg"]) for i, s in st.items()},
+            exp_avg_sq_norm={names[i]: l2(s["exp_avg_sq"]) for i, s in st.items()},
+            exp_avg_sample={names[i]: sample(s["exp_avg"]) for i, s in st.items()},
+            exp_avg_sq_sample={names[i]: sample(s["exp_avg_sq"]) for i, s in st.items()},
+            state_step=float(st[0]["step"]))
+        print(f"steps3_{name}: lr {[s['lr_after'] for s in steps]}")
+
+    # (2) eval-mode decoder: Autoencoder.sample(return_samples=True) with the torch.randn draw injected
+    small = dict(num_channels=16, latent_size=32)
+    for name, cfg, act in (("vae_cfg2_b8", base_cfg(), "gelu"),
+                           ("vae_pool_bilinear_b4", base_cfg(no_pool=False, no_upsample=False, interpolation="bilinear", **small), "gelu"),
+                           ("ae_nosigmoid_b4", base_cfg(variational=False, sigmoid=False, num_channels=32, latent_size=64), "relu")):
+        shape_cfg = dict(variational=cfg["variational"], latent_size=cfg["latent_size"], num_channels=cfg["num_channels"],
+                         kernel_size=3, no_pool=cfg["no_pool"], no_upsample=cfg["no_upsample"])
+        model = build_ref(cfg, detgen.ae_params(name, **shape_cfg), act)
+        z = T(detgen.normal(f"{name}/sample_z", (5, cfg["latent_size"])))
+        with torch.no_grad():
+            s = _with_patched("randn", _Queue([z]), lambda: model.sample(num_images=5, return_samples=True))
+        assert not model.training
+        out[f"sample_{name}"] = dict(n=5, sample=sample(s), l2=l2(s), shape=list(s.shape))
+        print(f"sample_{name}: l2 {l2(s):.6f}")
+
+    # (3) the epoch loop: train_one_epoch (3 batches) then compute_test_loss (2 batches)
+    for name, variational, mse in (("epoch_vae", True, False), ("epoch_vae_msep", True, True), ("epoch_ae", False, False)):
+        cfg = base_cfg(variational=variational, num_channels=32, latent_size=64)
+        shape_cfg = dict(variational=variational, latent_size=64, num_channels=32, kernel_size=3, no_pool=True, no_upsample=True)
+        model = build_ref(cfg, detgen.ae_params(name, **shape_cfg), "gelu")
+        optim = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+        sched = torch.optim.lr_scheduler.CosineAnnealingLR(optim, T_max=6)
+        args = types.SimpleNamespace(variational=variational, mse=mse, beta_mult=1.02)
+        tr, te, etr, ete = _epoch_inputs(name, variational, 64, 3, 2, 8)
+        beta0 = 0.01
+        beta, tr_rec, tr_kl = ref_train_one_epoch(args, model, beta0, [T(a) for a in tr], [T(e) for e in etr], optim, sched)
+        lm, ls, te_rec, te_kl = ref_compute_test_loss(args, model, beta, [T(a) for a in te], [T(e) for e in ete])
+        out[name] = dict(variational=variational, mse=mse, B=8, nb_train=3, nb_test=2, beta0=beta0, beta_mult=1.02, T_max=6,
+                         beta_after=float(beta), train_rec=float(tr_rec), train_kl=float(tr_kl), lr_after=sched.get_last_lr()[0],
+                         latent_mean=float(lm), latent_std=float(ls), test_rec=float(te_rec), test_kl=float(te_kl),
+                         param_norm={k: l2(p.detach()) for k, p in model.named_parameters()},
+                         param_sample={k: sample(p.detach()) for k, p in model.named_parameters()})
+        print(f"{name}: beta {beta:.6f} train rec {float(tr_rec):.6f} kl {float(tr_kl):.6f} test rec {float(te_rec):.6f} "
+              f"kl {float(te_kl):.6f} mean {float(lm):.5f} std {float(ls):.5f}")
+
+    # (4) files written by the REFERENCE's classes: a full-model pickle (what --ae_checkpoint loads, main.py:189-195,338-339)
+    # and a resume checkpoint (main.py:217-222, 323-334).  Tiny configs so that the fixtures stay small.
+    tiny = dict(num_channels=8, latent_size=16)
+    for name, cfg in (("refpickle_ae_deconv", base_cfg(variational=False, **tiny)),
+                      ("refpickle_ae_pool_bilinear", base_cfg(variational=False, no_pool=False, no_upsample=False,
+                                                              interpolation="bilinear", **tiny))):
+        shape_cfg = dict(variational=False, latent_size=16, num_channels=8, kernel_size=3, no_pool=cfg["no_pool"],
+                         no_upsample=cfg["no_upsample"])
+        model = build_ref(cfg, detgen.ae_params(name, **shape_cfg), "gelu")
+        model.eval()
+        x = T(detgen.images(name, 4))
+        with torch.no_grad():
+            recon = model(x)
+        torch.save(model, os.path.join(OUT, name + ".pth"))   # full-model pickle of models.autoencoders.Autoencoder
+        out[name] = dict(recon_sample=sample(recon), recon_l2=l2(recon), latent_sample=sample(model.latent_vector),
+                         keys=list(model.state_dict().keys()))
+    name = "refckpt_vae"
+    cfg = base_cfg(**tiny)
+    shape_cfg = dict(variational=True, latent_size=16, num_channels=8, kernel_size=3, no_pool=True, no_upsample=True)
+    model = build_ref(cfg, detgen.ae_params(name, **shape_cfg), "gelu")
+    optim = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(optim, T_max=6)
+    args = types.SimpleNamespace(variational=True, mse=False, beta_mult=1.02)
+    tr, _, etr, _ = _epoch_inputs(name, True, 16, 3, 0, 4)
+    beta, _, _ = ref_train_one_epoch(args, model, 0.01, [T(a) for a in tr[:2]], [T(e) for e in etr[:2]], optim, sched)
+    ck = dict(state_dict=model.state_dict(), optimizer=optim.state_dict(), lr_scheduler=sched.state_dict(), epoch=0,
+              current_beta=beta, losses="")     # keys of main.py:323-331 minus `args` (it pickles an nn.Module instance)
+    torch.save(ck, os.path.join(OUT, name + ".pth"))
+    args.beta_mult = 1.0
+    _, rec, kl = ref_train_one_epoch(args, model, beta, [T(tr[2])], [T(etr[2])], optim, sched)   # the step after resume
+    out[name] = dict(beta=float(beta), rec=float(rec), beta_kl=float(kl), lr_after=sched.get_last_lr()[0],
+                     param_sample={k: sample(p.detach()) for k, p in model.named_parameters()},
+                     param_norm={k: l2(p.detach()) for k, p in model.named_parameters()})
+    with open(os.path.join(OUT, "train_extra.json"), "w") as f:
+        json.dump(out, f, separators=(',', ':'))
+    print("extra goldens written")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":
+        gen_extra()
+        raise SystemExit
     if len(sys.argv) > 1 and sys.argv[1] == "classifier":
         gen_classifier()
         raise SystemExit
     gen_train()
     gen_metrics()
     gen_classifier()
+    gen_extra()
     print("goldens written to", OUT)

@@ -30,3 +30,10 @@ def train_golden():
 @pytest.fixture(scope="session")
 def metrics_golden():
     return load_golden("metrics.json")
+
+
+@pytest.fixture(scope="session")
+def extra_golden():
+    """Round-2 fixtures from the imported reference: multi-step optimizer runs, eval-mode samples, the epoch loop,
+    reference-written pickles (oracle/gen_golden.py gen_extra)."""
+    return load_golden("train_extra.json")

@@ -1,5 +1,6 @@
 """CPU, world_size 2, gloo: the data-parallel plumbing (flat gradient buckets, overlapped all-reduce
-bookkeeping, FID moment exchange) is correct by construction.  No kernels run here."""
+bookkeeping, FID / IS moment exchange through the product's metrics module) is correct by construction.  No kernels
+run here; the same path with the kernels runs in tests/test_dp_equiv_gpu.py (two ranks on the GPU)."""
 import os
 import sys
 
@@ -48,20 +49,56 @@ def _worker(rank, world, port, q):
         expect = sum(both)
         assert torch.allclose(opt.flat_grad, expect, atol=1e-6)
         assert abs(opt.grad_scale - 1.0 / world) < 1e-12          # the mean is folded into AdamW
-        # FID moments: one all-reduce of the packed (n, s, G)
+        # FID / IS exchange steps: the PRODUCT host path (metrics.feature_moments / _logit_stats with sharded=True), with
+        # the two HIP kernels replaced by CPU stand-ins of their documented contract (include/gmk.h) -- no GPU here
+        import metrics
+        from gmk import ops
+
+        def cpu_gram(x, G, s):
+            xd = x.double()
+            G += xd.T @ xd
+            s += xd.sum(0)
+
+        def cpu_softmax_stats(logits, out=None, topn=3, eps=1e-7):
+            n, C = logits.shape
+            if out is None:
+                out = torch.zeros(2 * C + 4, dtype=torch.float64)
+            p = torch.softmax(logits.double(), dim=1)
+            out[:C] += p.sum(0)
+            out[C:2 * C] += torch.bincount(p.argmax(1), minlength=C).double()
+            out[2 * C] += -(p * torch.log(p + eps)).sum()
+            out[2 * C + 1] += p.max(1)[0].sum()
+            out[2 * C + 2] += p.sort(1, descending=True)[0][:, :topn].sum()
+            out[2 * C + 3] += n
+            return out
+
+        ops.gram_accumulate, ops.softmax_stats = cpu_gram, cpu_softmax_stats
+
+        class Feat(torch.nn.Module):
+            def forward(self, x):
+                self.latent_vector = x
+                return x
+
         D = 16
-        feats = torch.randn(40 + 10 * rank, D, generator=torch.Generator().manual_seed(7 + rank)).double()
-        packed = torch.zeros(1 + D + D * D, dtype=torch.float64)
-        packed[0] = feats.shape[0]
-        packed[1:1 + D] = feats.sum(0)
-        packed[1 + D:] = (feats.T @ feats).reshape(-1)
-        dist.all_reduce(packed)
-        allf = torch.cat([torch.randn(40 + 10 * r, D, generator=torch.Generator().manual_seed(7 + r)).double() for r in range(world)])
-        assert int(packed[0]) == allf.shape[0]
-        n = allf.shape[0]
-        mu = packed[1:1 + D] / n
-        sigma = (packed[1 + D:].view(D, D) - n * torch.outer(mu, mu)) / (n - 1)
+        sizes = [40 + 10 * r for r in range(world)]
+        feats = [torch.randn(n, D, generator=torch.Generator().manual_seed(7 + r)) for r, n in enumerate(sizes)]
+        n, sv, G = metrics.feature_moments(Feat(), feats[rank], batch_size=16, group=None, sharded=True)
+        allf = torch.cat(feats).double()
+        assert n == allf.shape[0]
+        mu = sv / n
+        sigma = (G - n * torch.outer(mu, mu)) / (n - 1)
         assert np.allclose(sigma.numpy(), np.cov(allf.numpy(), rowvar=False), atol=1e-10)
+        n_local, _, G_local = metrics.feature_moments(Feat(), feats[rank], batch_size=16)      # reference call shape:
+        assert n_local == sizes[rank]                                                          # no collective
+        from oracle import metrics_oracle
+        logits = [torch.randn(30 + 5 * r, 10, generator=torch.Generator().manual_seed(70 + r)) * 3 for r in range(world)]
+        ident = torch.nn.Identity()
+        is_ = metrics.compute_inception_score(ident, logits[rank], sharded=True)
+        conf, div = metrics.compute_confidence_diversity(ident, logits[rank], sharded=True)
+        full = torch.cat(logits)
+        c_ref, d_ref, _ = metrics_oracle.confidence_diversity(full)
+        assert abs(float(is_) - float(metrics_oracle.inception_score(full))) < 1e-5
+        assert abs(float(conf) - float(c_ref)) < 1e-4 and abs(float(div) - float(d_ref)) < 1e-4
         # the kernel step must refuse to run on CPU (no fallback path)
         try:
             opt.step()
