@@ -11,6 +11,7 @@ extern "C" const char* gmk_strerror(int code) {
     case GMK_E_UNSUPPORTED: return "gmk: unsupported option";
     case GMK_E_WORKSPACE: return "gmk: workspace too small";
     case GMK_E_NULL: return "gmk: required pointer is NULL";
+    case GMK_E_TOO_LARGE: return "gmk: input exceeds the stated maximum of this allocation-free entry point";
     default: break;
   }
   if (code > 0) return hipGetErrorString((hipError_t)code);

@@ -3,6 +3,7 @@
 // write dpre, read stats, write dstats.  One pass, float4 per lane, wave64 shuffle reduction,
 // per-block fp64 partials, fixed-order 1-block finalize (deterministic).
 #include "gmk_common.h"
+#include <mutex>
 
 #define LOSS_BLOCKS 1024
 #define LOSS_THREADS 256
@@ -158,6 +159,51 @@ extern "C" int gmk_vae_loss_eval(const float* pre, const float* image, const flo
                                  size_t ws_bytes, gmk_stream_t stream) {
   return vae_loss_launch(pre, image, stats, recon_out, nullptr, nullptr, out5, B, chw, L, beta, flags, ws, ws_bytes,
                          stream, false);
+}
+
+// ---- allocation-free entry point ---------------------------------------------------------------
+// gmk_vae_loss_fwd_bwd_static: the same two kernels, with the block partials in a file-scope __device__ array
+// instead of a caller workspace, for callers that can neither allocate nor carry a workspace (HIP graph capture,
+// serving loops).  The array's name is only a host-side stand-in: the device address is resolved once per device
+// with hipGetSymbolAddress (each GPU holds its own copy at its own address) and that pointer -- never the name --
+// is what the kernels receive.  Nothing in it has to start at zero: every block overwrites its own partial slots
+// and the finalize kernel reads only the slots of the blocks that ran.  Calls that overlap on one GPU (two streams)
+// share the array and race; calls on one stream are ordered.
+#define GMK_LOSS_STATIC_MAX_DEVICES 64
+static __device__ __align__(256) double scratch[4 * LOSS_BLOCKS];   // 32 KiB per GPU, held until the process ends
+static double* g_scratch_ptr[GMK_LOSS_STATIC_MAX_DEVICES];          // per-device address of `scratch`
+static std::mutex g_scratch_mu;
+
+static int loss_scratch_ptr(double** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  GMK_REQUIRE(dev >= 0 && dev < GMK_LOSS_STATIC_MAX_DEVICES, GMK_E_UNSUPPORTED);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {   // first call on this device (it is the current one): resolve and keep the address
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return (int)e;
+    GMK_REQUIRE(p != nullptr, GMK_E_NULL);
+    g_scratch_ptr[dev] = (double*)p;
+  }
+  *out = g_scratch_ptr[dev];
+  return GMK_OK;
+}
+
+extern "C" int gmk_vae_loss_fwd_bwd_static(const float* pre, const float* image, const float* stats,
+                                           float* recon_out, float* dpre, float* dstats, float* losses, int64_t B,
+                                           int64_t chw, int64_t L, float beta, int flags, gmk_stream_t stream) {
+  GMK_REQUIRE(B > 0 && chw > 0 && L >= 0, GMK_E_SHAPE);
+  // stated maximum: 2^28 elements per tensor (1 GiB of fp32; 87,381 CIFAR images): within it a thread adds at most
+  // 1,024 fp32 terms before its sum goes to fp64
+  GMK_REQUIRE(B <= GMK_LOSS_STATIC_MAX_ELEMS && chw <= GMK_LOSS_STATIC_MAX_ELEMS && L <= GMK_LOSS_STATIC_MAX_ELEMS &&
+              B * chw <= GMK_LOSS_STATIC_MAX_ELEMS && B * L <= GMK_LOSS_STATIC_MAX_ELEMS, GMK_E_TOO_LARGE);
+  double* ptr = nullptr;
+  int rc = loss_scratch_ptr(&ptr);
+  if (rc != GMK_OK) return rc;
+  return vae_loss_launch(pre, image, stats, recon_out, dpre, dstats, losses, B, chw, L, beta, flags, ptr,
+                         sizeof(double) * 4 * LOSS_BLOCKS, stream, true);
 }
 
 // ---- reparameterisation ---------------------------------------------------------------

@@ -47,6 +47,7 @@ SIGNATURES = {
     "gmk_softmax_stats": (_I, [_P, _L, _I, _I, _F, _P, _P]),
     "gmk_vae_loss_workspace_bytes": (_Z, []),
     "gmk_vae_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _F, _I, _P, _Z, _P]),
+    "gmk_vae_loss_fwd_bwd_static": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _F, _I, _P]),
     "gmk_vae_loss_eval": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _F, _I, _P, _Z, _P]),
 }
 

@@ -33,7 +33,8 @@ enum gmk_error {
   GMK_E_ALIGN = -2,       /* pointer not 16-byte aligned */
   GMK_E_UNSUPPORTED = -3, /* unsupported option (kernel size, activation, mode) */
   GMK_E_WORKSPACE = -4,   /* workspace too small */
-  GMK_E_NULL = -5         /* required pointer is NULL */
+  GMK_E_NULL = -5,        /* required pointer is NULL */
+  GMK_E_TOO_LARGE = -6    /* input exceeds the stated maximum of an allocation-free (static scratch) entry point */
 };
 
 /* /root/reference/utils.py:49-66 get_activation_function */
@@ -137,6 +138,20 @@ int gmk_vae_loss_fwd_bwd(const float* pre, const float* image, const float* stat
 int gmk_vae_loss_eval(const float* pre, const float* image, const float* stats, float* recon_out,
                       float* out5, int64_t B, int64_t chw, int64_t L, float beta, int flags,
                       void* ws, size_t ws_bytes, gmk_stream_t stream);
+
+/* gmk_vae_loss_fwd_bwd_static: gmk_vae_loss_fwd_bwd without the workspace argument.  NO COUNTERPART IN THE
+ *   REFERENCE: it exists for callers that cannot allocate or carry a workspace -- code under HIP graph capture,
+ *   tight serving loops, harnesses that forbid hipMalloc.  The block partials live in a 32 KiB file-scope
+ *   __device__ array of the library (one copy per GPU, held until the process ends); the call allocates nothing
+ *   and frees nothing.  Same kernels and therefore bit-identical outputs.  Limits: B*chw and B*L at most
+ *   GMK_LOSS_STATIC_MAX_ELEMS (2^28) each, else GMK_E_TOO_LARGE.  The first call on a device resolves the array's
+ *   device address (hipGetSymbolAddress): make it outside graph capture, with that device current.  All calls on
+ *   one GPU share the array: calls on one stream are ordered, calls that overlap on different streams race. */
+#define GMK_LOSS_STATIC_MAX_ELEMS (1ll << 28)
+int gmk_vae_loss_fwd_bwd_static(const float* pre, const float* image, const float* stats,
+                                float* recon_out, float* dpre, float* dstats, float* losses,
+                                int64_t B, int64_t chw, int64_t L, float beta, int flags,
+                                gmk_stream_t stream);
 
 /* ---------------------------------------------------------------- pool / upsample -------
  * Pool + upsample variants of the autoencoder (models/autoencoders.py:40,48,52,89,100,104).
