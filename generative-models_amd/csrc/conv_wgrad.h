@@ -280,6 +280,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
     });
   }
 
+  // The last iteration's look-ahead loads (a clamped re-read, never stored) are invisible to the compiler: without this
+  // drain their data lands in registers that the reduction below already reuses.  Alone on the chip they return long
+  // before, but under the two-stream backward pass they did not always (run-to-run differences of 2e-2 in the parameters
+  // after 40 steps, tools/determinism.py); a kernel that ends with untracked loads in flight is wrong in any case.
+  gmk_vm_wait_all();
   if (g.dbg & 4) return;
   // ---- combine the four waves' partial tiles in LDS (fixed order), one slab per block ----
   // slab[(blockIdx.x * gridDim.y + blockIdx.y)][t][cb 32][cs 32] followed by 32 bias partials.

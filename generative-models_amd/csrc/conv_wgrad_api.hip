@@ -1,11 +1,19 @@
 // conv_wgrad_api.hip -- C-ABI entry points for conv / deconv weight + bias gradients.
 #include "conv_wgrad.h"
+#include "conv_wgrad16.h"
 #include "conv_wgrad_thin.h"
+
+// 3x3 layers run on the 16x16x4-MFMA kernel (conv_wgrad16.h); GMK_WG16=0 selects the older 32x32x2 kernel for A/B runs.
+static bool use_wg16(int N, int Cs, int Cb, int SH, int SW, int ksize, int sb) {
+  static const int on = getenv("GMK_WG16") ? atoi(getenv("GMK_WG16")) : 1;
+  return on && ksize == 3 && gmk_wg16_supported(N, Cs, Cb, SH, SW, sb);
+}
 
 static void wgrad_plan(WgradGeom& g, int N, int Cs, int Cb, int SH, int SW, int ksize, int sb) {
   g.N = N; g.Cs = Cs; g.Cb = Cb; g.SH = SH; g.SW = SW; g.BHt = SH * sb; g.BWt = SW * sb;
   g.lgSW = gmk_ilog2(SW); g.lgSHW = gmk_ilog2((int64_t)SH * SW); g.lgBWt = gmk_ilog2(g.BWt);
-  g.P = gmk_wgrad_patch(SW, ksize, sb).PX; g.lgP = gmk_ilog2(g.P);
+  g.P = use_wg16(N, Cs, Cb, SH, SW, ksize, sb) ? gmk_wg16_geo(SW, sb).PX : gmk_wgrad_patch(SW, ksize, sb).PX;
+  g.lgP = gmk_ilog2(g.P);
   g.total_chunks = ((long long)N * SH * SW) / g.P;
   g.csT = (Cs + GMK_WG_T - 1) / GMK_WG_T; g.cbT = (Cb + GMK_WG_T - 1) / GMK_WG_T;
   const int ntg = ksize == 3 ? 1 : ksize;
@@ -46,7 +54,8 @@ extern "C" size_t gmk_deconv2d_wgrad_workspace_bytes(int N, int Cin, int H, int 
 static int wgrad_run(const float* small, const float* big, float* dw, float* dbias, int bias_mode, int N, int Cs,
                      int Cb, int SH, int SW, int ksize, int sb, void* ws, size_t ws_bytes, hipStream_t s) {
   if (ksize != 3 && ksize != 5) return GMK_E_UNSUPPORTED;
-  if (!gmk_wgrad_supported(SH, SW, ksize, sb)) return GMK_E_SHAPE;  // square-ish power-of-two images, 8 <= width <= 64
+  const bool wg16 = use_wg16(N, Cs, Cb, SH, SW, ksize, sb);
+  if (!wg16 && !gmk_wgrad_supported(SH, SW, ksize, sb)) return GMK_E_SHAPE;  // square-ish power-of-two images, 8 <= width <= 64
   if (!gmk_aligned16(ws) || !gmk_aligned16(small) || !gmk_aligned16(big)) return GMK_E_ALIGN;
   WgradGeom g{};
   { static const int dbg = getenv("GMK_WG_DBG") ? atoi(getenv("GMK_WG_DBG")) : 0; g.dbg = dbg; }
@@ -54,6 +63,7 @@ static int wgrad_run(const float* small, const float* big, float* dw, float* dbi
   if (ws_bytes < slab_bytes(g, ksize)) return GMK_E_WORKSPACE;
   g.s = small; g.b = big; g.slab = (float*)ws;
   g.bias_mode = dbias ? bias_mode : 0;
+  if (wg16) return gmk_launch_wgrad16(g, sb, dw, dbias, s);
   return ksize == 3 ? gmk_launch_wgrad_k3(g, sb, dw, dbias, s) : gmk_launch_wgrad_k5(g, sb, dw, dbias, s);
 }
 

@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgmk.so")
+# GMK_LIB_PATH: another build of the same library (same-device A/B runs of kernel variants, tools/ only)
+LIB_PATH = os.environ.get("GMK_LIB_PATH") or os.path.join(HERE, "libgmk.so")
 
 ACT_IDS = {None: 0, "none": 0, "relu": 1, "leaky-relu": 2, "elu": 3, "selu": 4, "gelu": 5, "swish": 6, "mish": 7,
            "sigmoid": 8}

@@ -70,6 +70,16 @@ CONV_SHAPES = [
     (2, 16, 32, 32, 3, 5, 1),
     (1, 24, 64, 64, 2, 3, 1),
     (3, 8, 16, 16, 1, 3, 1),
+    # 3x3 weight-gradient kernel (conv_wgrad16.h): several chunks per block so that the double-buffered pipeline reaches
+    # its steady state and its look-ahead runs past the end (even / odd / ragged chunk counts per block), every width
+    (64, 64, 16, 16, 64, 3, 1),
+    (200, 32, 16, 16, 32, 3, 1),
+    (40, 64, 32, 32, 64, 3, 2),
+    (150, 64, 16, 16, 64, 3, 2),
+    (300, 32, 8, 8, 32, 3, 1),
+    (6, 64, 32, 32, 64, 3, 1),
+    (5, 16, 64, 64, 16, 3, 1),
+    (3, 40, 64, 64, 24, 3, 2),
 ]
 
 
@@ -125,7 +135,8 @@ def test_conv2d_dgrad_wgrad(shape):
 
 
 DECONV_SHAPES = [(2, 64, 8, 8, 64, 3), (2, 64, 16, 16, 64, 3), (3, 16, 8, 8, 24, 3), (1, 8, 8, 8, 8, 5), (9, 64, 16, 16, 64, 3),
-                 (2, 20, 8, 8, 12, 3), (2, 44, 16, 16, 100, 3)]  # K-chunk tails in every mode
+                 (2, 20, 8, 8, 12, 3), (2, 44, 16, 16, 100, 3),  # K-chunk tails in every mode
+                 (70, 64, 8, 8, 64, 3), (50, 64, 16, 16, 64, 3), (3, 24, 32, 32, 40, 3)]  # several chunks per wgrad block
 
 
 @pytest.mark.parametrize("shape", DECONV_SHAPES)
