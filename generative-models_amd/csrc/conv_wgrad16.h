@@ -132,16 +132,6 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(const WgradGeom g) {
     loff[NS + k] = PATCH0 + (live ? c * PSb + prow * PC + col : T * PSb) * 4;   // dead slots: the trash area behind the patch
     bmul[NS + k] = (bias2 && live && prow >= PAD && prow < PAD + (PX >> LGSW) * SB) ? 1.f : 0.f;
   }
-  // zero the halo words of every patch row in both buffers once (image data never lands there)
-  for (int e = tid; e < 2 * T * PR * (SB == 1 ? 2 : 1); e += 256) {
-    const int bufi = e & 1, rr = e >> 1;
-    const int side = SB == 1 ? rr & 1 : 0, r2 = SB == 1 ? rr >> 1 : rr;
-    const int c = r2 / PR, prow = r2 % PR;
-    float2* hz = (float2*)((char*)smem + bufi * BUFB + PATCH0 + (c * PSb + prow * PC + (side ? 4 + BWt : 0)) * 4);   // rows are 8-byte aligned
-    hz[0] = make_float2(0.f, 0.f);
-    hz[1] = make_float2(0.f, 0.f);
-  }
-
   // ---- MFMA operand bases (bytes, buffer 0) ------------------------------------------------------------
   const unsigned lds0 = gmk_lds_addr(smem);
   const unsigned addrA0 = lds0 + ((qs * 16 + i16) * SS + kq) * 4;
@@ -214,6 +204,15 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(const WgradGeom g) {
     gmk_i32x4 rs, rb_;
     chunk_soff(ch, so_s, so_b, r0s, rs, rb_);
     gmk_static_for<0, NSTG>([&](auto u_) { issue_load(u_, rs, rb_, so_s, so_b, r0s); });
+    // under the first loads' latency: zero the halo words of every patch row in both buffers (image data never lands there)
+    for (int e = tid; e < 2 * T * PR * (SB == 1 ? 2 : 1); e += 256) {
+      const int bufi = e & 1, rr = e >> 1;
+      const int side = SB == 1 ? rr & 1 : 0, r2 = SB == 1 ? rr >> 1 : rr;
+      const int c = r2 / PR, prow = r2 % PR;
+      float2* hz = (float2*)((char*)smem + bufi * BUFB + PATCH0 + (c * PSb + prow * PC + (side ? 4 + BWt : 0)) * 4);   // rows are 8-byte aligned
+      hz[0] = make_float2(0.f, 0.f);
+      hz[1] = make_float2(0.f, 0.f);
+    }
     gmk_vm_wait_all();
     gmk_static_for<0, NSTG>([&](auto u_) { write_slot(u_, 0u); });
     chunk_soff(ch + G, so_s, so_b, r0s, rs, rb_);
@@ -309,10 +308,12 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(const WgradGeom g) {
   }
 }
 
-// dW[cs][cb][t] = sum_g slab[g][tile][t][cb][cs], dbias from the 32 trailing floats: the same fixed-order sum as
-// conv_wgrad_reduce_kernel, without LDS.  A launch that uses shared memory cannot start on a CU whose 160 KB are
-// taken by the other stream's dgrad blocks; this one needs 24 registers and nothing else.  Lanes 0-31 of a wave take
-// the even slabs of 32 float4 elements, lanes 32-63 the odd slabs; one cross-lane add combines them.
+// dW[cs][cb][t] = sum_g slab[g][tile][t][cb][cs], dbias from the 32 trailing floats: a fixed-order sum like
+// conv_wgrad_reduce_kernel, without LDS (a launch that uses shared memory cannot start on a CU whose 160 KB are taken
+// by the other stream's dgrad blocks) and with the G slabs of an element spread over 8 lane groups: next to the
+// dgrad kernels every load takes 1-2 us, so the serial chain per thread has to be short (8 slabs = 2 batches of 4
+// loads instead of 32 slabs: 14 -> 5 us in the overlapped step).  Lane = group * 8 + element quad: 8 lanes read 128
+// contiguous bytes of one slab; three cross-lane adds combine the groups in the fixed order ((0+1)+(2+3))+((4+5)+(6+7)).
 template <int KS, int NT>
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_nolds_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                                       float* __restrict__ dbias, int G, int ny, int Cs,
@@ -322,21 +323,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_nolds_kernel(const floa
   const int tg = y % NTG, tile = y / NTG;
   const int cs0 = (tile / cbT) * T, cb0 = (tile % cbT) * T;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int el = lane & 31, par = lane >> 5;
-  const int e = ((blockIdx.x * 4 + wave) * 32 + el) * 4;
+  const int el = lane & 7, grp = lane >> 3;
+  const int e = ((blockIdx.x * 4 + wave) * 8 + el) * 4;   // first of this lane's 4 slab elements (bias tail included)
   float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e < SLAB) {
-    const float* src = slab + ((size_t)par * ny + y) * (size_t)SLAB + e;
-    const size_t step = (size_t)2 * ny * SLAB;
+    const float* src = slab + ((size_t)grp * ny + y) * (size_t)SLAB + e;
+    const size_t step = (size_t)8 * ny * SLAB;
 #pragma unroll 4
-    for (int gI = par; gI < G; gI += 2, src += step) {
+    for (int gI = grp; gI < G; gI += 8, src += step) {
       const float4 v = *(const float4*)src;
       sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
     }
   }
-  sum.x += __shfl_xor(sum.x, 32, 64); sum.y += __shfl_xor(sum.y, 32, 64);
-  sum.z += __shfl_xor(sum.z, 32, 64); sum.w += __shfl_xor(sum.w, 32, 64);
-  if (par != 0 || e >= SLAB) return;
+#pragma unroll
+  for (int o = 8; o <= 32; o <<= 1) {
+    sum.x += __shfl_xor(sum.x, o, 64); sum.y += __shfl_xor(sum.y, o, 64);
+    sum.z += __shfl_xor(sum.z, o, 64); sum.w += __shfl_xor(sum.w, o, 64);
+  }
+  if (grp != 0 || e >= SLAB) return;
   const float out[4] = {sum.x, sum.y, sum.z, sum.w};
   if (e < TILE) {
     const int t = e / (T * T), cb = (e / T) % T, cs = e % T;

@@ -18,7 +18,8 @@ static int launch16(WgradGeom& g, float* dw, float* dbias, hipStream_t s) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   constexpr int SLAB = 9 * GMK_WG_T * GMK_WG_T + GMK_WG_T;
-  hipLaunchKernelGGL((conv_wgrad_reduce_nolds_kernel<3, 9>), dim3((SLAB + 511) / 512, grid.y), dim3(256), 0, s, g.slab, dw,
+  if (g.dbg & 16) return GMK_OK;   // timing ablation (GMK_WG_DBG=16): no slab reduction, dw is not written
+  hipLaunchKernelGGL((conv_wgrad_reduce_nolds_kernel<3, 9>), dim3((SLAB + 127) / 128, grid.y), dim3(256), 0, s, g.slab, dw,
                      dbias, g.G, (int)grid.y, g.Cs, g.Cb, g.cbT, g.bias_mode);
   e = hipGetLastError();
   return e == hipSuccess ? GMK_OK : (int)e;

@@ -17,7 +17,9 @@ static void wgrad_plan(WgradGeom& g, int N, int Cs, int Cb, int SH, int SW, int 
   g.total_chunks = ((long long)N * SH * SW) / g.P;
   g.csT = (Cs + GMK_WG_T - 1) / GMK_WG_T; g.cbT = (Cb + GMK_WG_T - 1) / GMK_WG_T;
   const int ntg = ksize == 3 ? 1 : ksize;
-  long long want = 256 / ((long long)g.csT * g.cbT * ntg);  // one block per CU (128 / 192 / 384 / 512 blocks: 6-16 % slower steps)
+  static const int blocks16 = getenv("GMK_WG16_BLOCKS") ? atoi(getenv("GMK_WG16_BLOCKS")) : 256;   // A/B knob
+  const long long nblk = use_wg16(N, Cs, Cb, SH, SW, ksize, sb) ? blocks16 : 256;
+  long long want = nblk / ((long long)g.csT * g.cbT * ntg);  // one block per CU (128 / 192 / 384 / 512 blocks: 6-16 % slower steps)
   if (want < 16) want = 16;
   g.G = (int)(g.total_chunks < want ? g.total_chunks : want);
 }

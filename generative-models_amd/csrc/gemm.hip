@@ -15,6 +15,7 @@ enum { GEPI_NONE = 0, GEPI_BIAS_ACT = 1, GEPI_MUL = 2 };
 struct GemmArgs {
   const float* A; const float* B; float* C;
   const float* bias; const float* mul; float* dact;
+  const float* cs_src; float* cs_out; int cs_M, cs_N;   // column sums riding along: out[j] = sum_i src[i*cs_N + j] (bias gradient)
   int M, N, K;
   long long sai, sak, sbk, sbj;
   int ldc, epi, act;
@@ -98,10 +99,36 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 #define GLD 68  // LDS row stride (floats) of a [GK][64] tile: 16-byte rows for ds_write_b128
 // a_kfast / b_kfast: the operand is contiguous along k.  (A variant that issued ALL loads of a block's 128 / 256 deep K
 // range up front was measured and dropped: 128+ VGPRs halve the blocks per CU and the dgrad shapes got 30-50 % slower.)
+// Bias gradient of nn.Linear (column sums of dy) as extra blocks of the weight-gradient launch: block `cb` sums 64
+// columns, 4 row groups x 8 independent partial sums per thread, combined in a fixed order.
+__device__ __forceinline__ void gemm_colsum_block(const GemmArgs& g, int cb, float* red /* [4][64] */) {
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int j = cb * 64 + c;
+  float s[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s[u] = 0.f;
+  if (j < g.cs_N) {
+    int i = q;
+    for (; i + 28 < g.cs_M; i += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += g.cs_src[(size_t)(i + 4 * u) * g.cs_N + j];
+    }
+    for (; i < g.cs_M; i += 4) s[0] += g.cs_src[(size_t)i * g.cs_N + j];
+  }
+  red[q * 64 + c] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  __syncthreads();
+  if (q == 0 && j < g.cs_N) g.cs_out[j] = (red[c] + red[64 + c]) + (red[128 + c] + red[192 + c]);
+}
+
 template <bool a_kfast, bool b_kfast>
 __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[2][2][GK * GLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntx = (g.N + GT - 1) / GT;
+  if ((int)blockIdx.x >= ntx) {   // column-sum blocks (block-uniform branch)
+    if (blockIdx.y == 0 && blockIdx.z == 0) gemm_colsum_block(g, blockIdx.x - ntx, &smem[0][0][0]);
+    return;
+  }
   const int wr = wave >> 1, wc = wave & 1;
   const int h = lane >> 5, l31 = lane & 31;
   const int i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
@@ -143,7 +170,13 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const GemmArgs g) {
       b_k[u] = k; b_l[u] = k * GLD + q * 4;
     }
   }
-  float4 arr[1][2], brr[1][2];
+  // Register prefetch ring, GPD chunks deep.  One chunk of MFMA work is ~0.5-1 us per CU, a global load under load takes
+  // 1.5-2 us: with the next chunk only (round 1) every iteration of these short-K GEMMs waited out most of a load
+  // (2.2 us per chunk measured); four chunks ahead the loads are back when their turn comes.  Chunks past the end of
+  // the K range are clamped for the load and zeroed on their way into LDS, so the loop runs a multiple of GPD chunks
+  // without a branch around any load.
+  constexpr int GPD = 4;
+  float4 arr[GPD][2], brr[GPD][2];
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_chunk_to = [&](int k0, float4* ar, float4* br) {
 #pragma unroll
@@ -185,15 +218,20 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const GemmArgs g) {
     }
   };
   {
-    load_chunk_to(kbeg, arr[0], brr[0]);
+    const int nch = (kend - kbeg + GK - 1) / GK;
+#pragma unroll
+    for (int u = 0; u < GPD; ++u) load_chunk_to(kbeg + u * GK, arr[u], brr[u]);
     store_chunk_from(kbeg, 0, arr[0], brr[0]);
-    int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += GK, buf ^= 1) {
-      const bool more = k0 + GK < kend;  // uniform
-      if (more) load_chunk_to(k0 + GK, arr[0], brr[0]);
-      gmk_lds_barrier();  // tile `buf` is complete; the other tile's readers (previous iteration) are done
-      mfma_chunk(buf);
-      if (more) store_chunk_from(k0 + GK, buf ^ 1, arr[0], brr[0]);
+    load_chunk_to(kbeg + GPD * GK, arr[0], brr[0]);
+    for (int i = 0; i < nch; i += GPD) {
+#pragma unroll
+      for (int u = 0; u < GPD; ++u) {   // chunk c = i + u lives in LDS tile u & 1 (GPD is even), chunk c + 1 in ring slot (u + 1) % GPD
+        const int k1 = kbeg + (i + u + 1) * GK;
+        gmk_lds_barrier();  // tile u & 1 is complete; the other tile's readers (previous chunk) are done
+        mfma_chunk(u & 1);
+        store_chunk_from(k1, (u + 1) & 1, arr[(u + 1) % GPD], brr[(u + 1) % GPD]);
+        load_chunk_to(k1 + GPD * GK, arr[(u + 1) % GPD], brr[(u + 1) % GPD]);
+      }
     }
   }
   const int j = j0 + wc * 32 + l31;
@@ -261,10 +299,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ t
   if (q == 0 && j < N) out[j] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
+// Split K only while the grid is smaller than one block per CU: every split costs a slab round trip (8 MB written and
+// read back at these shapes) and a reduce launch, which is more than a second wave of blocks buys (round 1 split up to
+// 512 blocks: the M = 256 layers with 256 tiles then ran 12-20 us + a 5-9 us reduce each).
 static int pick_splits(int M, int N, int K) {
   const int tiles = ((M + GT - 1) / GT) * ((N + GT - 1) / GT);
   int splits = 1;
-  while (tiles * splits < 512 && K / (splits * 2) >= 128 && splits < 64) splits *= 2;
+  while (tiles * splits < 256 && K / (splits * 2) >= 128 && splits < 64) splits *= 2;
   return splits;
 }
 
@@ -285,6 +326,7 @@ static int run_gemm(GemmArgs g, void* ws, size_t ws_bytes, hipStream_t s) {
   g.kper = kper;
   const int zs = (g.K + kper - 1) / kper;
   dim3 grid((g.N + GT - 1) / GT, (g.M + GT - 1) / GT, zs);
+  const bool want_cs = g.cs_src != nullptr;
   if (zs > 1) {
     if (!ws || ws_bytes < sizeof(float) * (size_t)zs * g.M * g.N) return GMK_E_WORKSPACE;
     g.slab = (float*)ws;
@@ -295,7 +337,9 @@ static int run_gemm(GemmArgs g, void* ws, size_t ws_bytes, hipStream_t s) {
   const bool a_k = g.sak == 1, b_k = g.sbk == 1;
   const bool a_fast = a_k ? (g.K % 4 == 0 && g.sai % 4 == 0) : (g.sai == 1 && g.M % 4 == 0 && g.sak % 4 == 0);
   const bool b_fast = b_k ? (g.K % 4 == 0 && g.sbj % 4 == 0) : (g.sbj == 1 && g.N % 4 == 0 && g.sbk % 4 == 0);
+  bool cs_done = false;
   if (a_fast && b_fast && gmk_aligned16(g.A) && gmk_aligned16(g.B) && g.K >= 4) {
+    if (want_cs) { grid.x += (g.cs_N + 63) / 64; cs_done = true; }   // column-sum blocks ride in the same launch
     if (a_k && b_k) hipLaunchKernelGGL((gemm_f32_pipe_kernel<true, true>), grid, dim3(256), 0, s, g);
     else if (a_k) hipLaunchKernelGGL((gemm_f32_pipe_kernel<true, false>), grid, dim3(256), 0, s, g);
     else if (b_k) hipLaunchKernelGGL((gemm_f32_pipe_kernel<false, true>), grid, dim3(256), 0, s, g);
@@ -308,6 +352,11 @@ static int run_gemm(GemmArgs g, void* ws, size_t ws_bytes, hipStream_t s) {
     size_t total = (size_t)g.M * g.N;
     int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, g, zs);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  if (want_cs && !cs_done) {   // unaligned shapes (generic kernel): separate column-sum launch
+    hipLaunchKernelGGL(colsum_kernel, dim3((g.cs_N + 63) / 64), dim3(256), 0, s, g.cs_src, g.cs_out, g.cs_M, g.cs_N);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
@@ -345,11 +394,6 @@ extern "C" int gmk_linear_wgrad(const float* dy, const float* x, float* dw, floa
   g.A = dy; g.B = x; g.C = dw; g.bias = nullptr; g.dact = nullptr; g.mul = nullptr;
   g.M = N; g.N = K; g.K = M; g.sai = 1; g.sak = N; g.sbk = K; g.sbj = 1; g.ldc = K;
   g.epi = GEPI_NONE; g.act = 0;
-  int rc = run_gemm(g, ws, ws_bytes, (hipStream_t)stream);
-  if (rc) return rc;
-  if (dbias) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, dy, dbias, M, N);
-    GMK_CHECK_LAUNCH();
-  }
-  return GMK_OK;
+  if (dbias) { g.cs_src = dy; g.cs_out = dbias; g.cs_M = M; g.cs_N = N; }
+  return run_gemm(g, ws, ws_bytes, (hipStream_t)stream);
 }

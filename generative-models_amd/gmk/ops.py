@@ -50,21 +50,36 @@ class SideQueue:
         # stream priority knob (GMK_SIDE_PRIORITY=-1 = high): measured 2 % slower than equal priorities on one device,
         # so the default stays 0
         prio = int(os.environ.get("GMK_SIDE_PRIORITY", "0"))
-        self.stream = torch.cuda.Stream(device, priority=prio)
+        # GMK_SIDE_STREAMS=n: the weight-gradient launches alternate over n side streams (default 1)
+        n = max(1, int(os.environ.get("GMK_SIDE_STREAMS", "1")))
+        self.streams = [torch.cuda.Stream(device, priority=prio) for _ in range(n)]
+        self.stream = self.streams[0]
+        self._next = 0
         self._keep = []
 
     def run(self, fn, *tensors):
-        """fn() is enqueued on the side stream after everything enqueued so far on the current stream."""
+        """fn() is enqueued on a side stream after everything enqueued so far on the current stream."""
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
-        self.stream.wait_event(ev)
+        st = self.streams[self._next]
+        self._next = (self._next + 1) % len(self.streams)
+        st.wait_event(ev)
         self._keep.extend(tensors)
-        with torch.cuda.stream(self.stream):
+        with torch.cuda.stream(st):
             return fn()
+
+    def gather(self):
+        """Orders streams[0] behind the other side streams (so that work enqueued on it next, e.g. a gradient bucket's
+        all-reduce, sees every weight gradient launched so far)."""
+        for st in self.streams[1:]:
+            self.stream.wait_stream(st)
 
     def join(self):
         """The current stream waits for all side work; kept tensors may be freed afterwards."""
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        cur = torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            cur.wait_stream(st)
+        self._next = 0
         self._keep.clear()
 
 

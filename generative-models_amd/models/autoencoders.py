@@ -324,7 +324,8 @@ class Autoencoder(nn.Module):
                 return
             if side is None:
                 reducer.ready(name)
-            else:  # the bucket's gradients are ordered on the side stream: the all-reduce waits for that stream
+            else:  # the bucket's gradients are ordered on the side stream(s): the all-reduce waits for them
+                side.gather()
                 with torch.cuda.stream(side.stream):
                     reducer.ready(name)
 
