@@ -9,6 +9,7 @@
 //                        no Schur form), all on the device, no host sync.
 //  gmk_softmax_stats     fused softmax + entropy + top-1/top-N + arg-max histogram partial sums.
 #include "gmk_common.h"
+#include <stdlib.h>
 
 // =============================================================== Gram accumulation ==========
 #define GR_TILE 64   // output tile (features) per block
@@ -89,15 +90,158 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restri
   }
 }
 
+// ---- Gram accumulation, second version: 128 x 128 feature tiles, upper triangle only --------------------------
+// The 64 x 64 kernel above computes both triangles, re-reads X once per tile pair (5x the algorithmic bytes at
+// D = 256: 258 MB per 50,000 x 256 launch under rocprofv3 --pmc) and waits out every chunk's global loads
+// (fp64-MFMA busy 25 %).  Here a block owns a 128 x 128 tile (ti <= tj; 3 tiles at D = 256, so X is read twice), each
+// wave a 64 x 64 quadrant = 16 MFMA tiles fed by 4 + 4 operand reads per k-step; chunks of 32 samples go through
+// double-buffered LDS with the next chunk prefetched in registers (one LDS-only barrier per chunk).  The lower
+// triangle is mirrored by the reduce kernel.  Needs D % 4 == 0 (float4 rows); other D take the kernel above.
+#define G2_T 128
+#define G2_KC 32
+#define G2_STR 272   // LDS row [i-tile 128 | j-tile 128 | pad 16]: 272 = 16 (mod 32), so 16 features x 2 samples hit 32 banks
+
+__global__ __launch_bounds__(256) void gram_partial128_kernel(const float* __restrict__ X, long long n, int D,
+                                                              double* __restrict__ partial, double* __restrict__ psum,
+                                                              int splits, long long per) {
+  __shared__ __attribute__((aligned(16))) float Xl[2][G2_KC * G2_STR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  // upper-triangular tile index -> (ti, tj), ti <= tj
+  const int T = (D + G2_T - 1) / G2_T;
+  int ti = 0, rem = blockIdx.x;
+  while (rem >= T - ti) { rem -= T - ti; ++ti; }
+  const int tj = ti + rem;
+  const int i0 = ti * G2_T, j0 = tj * G2_T;
+  const int sp = blockIdx.y;
+  const long long kbeg = sp * per, kend = kbeg + per < n ? kbeg + per : n;
+
+  // staging: 8 float4 per thread and chunk; element e = tid + u*256 -> sample k = e / 64, quad q = e % 64 of the
+  // 256 staged columns (q < 32: i-tile, else j-tile)
+  int s_k[8], s_col[8], s_lds[8];
+  bool s_cok[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int e = tid + u * 256, k = e >> 6, q = e & 63;
+    const int col = (q < 32 ? i0 : j0 - 128) + 4 * q;   // global feature index of the quad
+    s_k[u] = k;
+    s_cok[u] = col < D;
+    s_col[u] = s_cok[u] ? col : 0;
+    s_lds[u] = k * G2_STR + 4 * q;
+  }
+  float4 pre[8];
+  auto load_chunk = [&](long long k0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      long long k = k0 + s_k[u];
+      k = k < n ? k : n - 1;   // clamped address, zeroed on the way into LDS: no load sits under a branch
+      pre[u] = *(const float4*)(X + k * D + s_col[u]);
+    }
+  };
+  auto store_chunk = [&](long long k0, int buf) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool ok = s_cok[u] && (k0 + s_k[u] < kend);
+      *(float4*)(&Xl[buf][s_lds[u]]) = ok ? pre[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  f64x4 acc[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  double csum = 0.0;   // column sum of feature i0 + tid (threads 0..127 of the diagonal tiles)
+  const bool do_sum = (ti == tj) && tid < G2_T;
+
+  if (kbeg < kend) {
+    load_chunk(kbeg);
+    store_chunk(kbeg, 0);
+    load_chunk(kbeg + G2_KC);
+    int buf = 0;
+    for (long long k0 = kbeg; k0 < kend; k0 += G2_KC, buf ^= 1) {
+      gmk_lds_barrier();                       // tile `buf` is complete; last chunk's readers of the other tile are done
+      store_chunk(k0 + G2_KC, buf ^ 1);        // (past the end: zeros into a tile nobody reads)
+      load_chunk(k0 + 2 * G2_KC);
+      const float* Xb = Xl[buf];
+      if (do_sum) {
+        double s = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < G2_KC; ++k) s += (double)Xb[k * G2_STR + tid];
+        csum += s;
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < G2_KC / 4; ++s4) {
+        const float* row = Xb + (4 * s4 + l4) * G2_STR + l15;
+        double a[4], b[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = (double)row[wi * 64 + r * 16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) b[c] = (double)row[128 + wj * 64 + c * 16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], b[c], acc[r][c], 0, 0, 0);
+      }
+    }
+  }
+  // f64 16x16x4 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+  double* out = partial + (size_t)sp * D * D;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + wi * 64 + r * 16 + l4 + 4 * q, j = j0 + wj * 64 + c * 16 + l15;
+        if (i < D && j < D) out[(size_t)i * D + j] = acc[r][c][q];
+      }
+  if (do_sum && i0 + tid < D) psum[(size_t)sp * D + i0 + tid] = csum;
+}
+
+// G += sum_z partial[z] over the upper tiles, mirrored into the lower tiles; s += sum_z psum[z].  Fixed order.
+__global__ __launch_bounds__(256) void gram_reduce128_kernel(const double* __restrict__ partial, const double* __restrict__ psum,
+                                                             double* __restrict__ G, double* __restrict__ s, int D, int splits) {
+  const size_t total = (size_t)D * D;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total + D; e += (size_t)gridDim.x * 256) {
+    double v = 0.0;
+    if (e < total) {
+      const int i = (int)(e / D), j = (int)(e % D);
+      if (i / G2_T > j / G2_T) continue;   // lower tiles are written by their mirror element
+      for (int z = 0; z < splits; ++z) v += partial[(size_t)z * total + e];
+      G[e] += v;
+      if (i / G2_T < j / G2_T) G[(size_t)j * D + i] += v;
+    } else {
+      const size_t j = e - total;
+      for (int z = 0; z < splits; ++z) v += psum[(size_t)z * D + j];
+      s[j] += v;
+    }
+  }
+}
+
 static int gram_splits(long long n) {
   long long s = n / 256;
   if (s < 1) s = 1;
   if (s > 32) s = 32;
   return (int)s;
 }
+// splits and samples per split of the 128-tile kernel: about one block per CU, at least two chunks per block
+static void gram128_plan(long long n, int D, int* splits, long long* per) {
+  const int T = (D + G2_T - 1) / G2_T, tiles = T * (T + 1) / 2;
+  long long s = 256 / tiles;
+  if (s < 1) s = 1;
+  if (s > n / 64) s = n / 64;
+  if (s < 1) s = 1;
+  long long p = ((n + s - 1) / s + G2_KC - 1) / G2_KC * G2_KC;
+  *per = p;
+  *splits = (int)((n + p - 1) / p);
+}
 
 extern "C" size_t gmk_gram_workspace_bytes(int64_t n, int D) {
-  return sizeof(double) * (size_t)gram_splits(n) * ((size_t)D * D + D) + 256;
+  int splits = gram_splits(n);
+  if (D % 4 == 0) { long long per; gram128_plan(n, D, &splits, &per); }
+  return sizeof(double) * (size_t)splits * ((size_t)D * D + D) + 256;
 }
 
 extern "C" int gmk_gram_accumulate(const float* X, int64_t n, int D, double* G, double* s, void* ws, size_t ws_bytes,
@@ -105,15 +249,29 @@ extern "C" int gmk_gram_accumulate(const float* X, int64_t n, int D, double* G, 
   GMK_REQUIRE(X && G && s && ws, GMK_E_NULL);
   GMK_REQUIRE(n > 0 && D > 0 && D <= 4096, GMK_E_SHAPE);
   GMK_REQUIRE(ws_bytes >= gmk_gram_workspace_bytes(n, D) - 256, GMK_E_WORKSPACE);
+  hipStream_t st = (hipStream_t)stream;
+  size_t total = (size_t)D * D + D;
+  int blocks = (int)((total + 255) / 256); if (blocks > 1024) blocks = 1024;
+  static const int old = getenv("GMK_GRAM64") ? atoi(getenv("GMK_GRAM64")) : 0;   // A/B knob: the 64 x 64 kernel
+  if (D % 4 == 0 && gmk_aligned16(X) && !old) {
+    int splits; long long per;
+    gram128_plan(n, D, &splits, &per);
+    const int T = (D + G2_T - 1) / G2_T;
+    double* partial = (double*)ws;
+    double* psum = partial + (size_t)splits * D * D;
+    hipLaunchKernelGGL(gram_partial128_kernel, dim3(T * (T + 1) / 2, splits), dim3(256), 0, st, X, (long long)n, D, partial,
+                       psum, splits, per);
+    GMK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gram_reduce128_kernel, dim3(blocks), dim3(256), 0, st, partial, psum, G, s, D, splits);
+    GMK_CHECK_LAUNCH();
+    return GMK_OK;
+  }
   const int splits = gram_splits(n);
   const int tiles = (D + GR_TILE - 1) / GR_TILE;
   double* partial = (double*)ws;
   double* psum = partial + (size_t)splits * D * D;
-  hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gram_partial_kernel, dim3(tiles * tiles, splits), dim3(256), 0, st, X, (long long)n, D, partial, psum, splits);
   GMK_CHECK_LAUNCH();
-  size_t total = (size_t)D * D + D;
-  int blocks = (int)((total + 255) / 256); if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(gram_reduce_kernel, dim3(blocks), dim3(256), 0, st, partial, psum, G, s, D, splits);
   GMK_CHECK_LAUNCH();
   return GMK_OK;
