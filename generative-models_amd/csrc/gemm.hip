@@ -10,12 +10,15 @@
 #define AS_STRIDE 33
 #define BS_STRIDE 65
 
-enum { GEPI_NONE = 0, GEPI_BIAS_ACT = 1, GEPI_MUL = 2 };
+enum { GEPI_NONE = 0, GEPI_BIAS_ACT = 1, GEPI_MUL = 2, GEPI_REPARAM_FWD = 3, GEPI_REPARAM_BWD = 4 };
 
 struct GemmArgs {
   const float* A; const float* B; float* C;
   const float* bias; const float* mul; float* dact;
-  const float* cs_src; float* cs_out; int cs_M, cs_N;   // column sums riding along: out[j] = sum_i src[i*cs_N + j] (bias gradient)
+  const float* cs_src; float* cs_out; int cs_M, cs_N;
+  // VAE tail fused into the split-K reduction (GEPI_REPARAM_*): eps (M, L); FWD: C = stats (M, 2L), z (M, L) out;
+  // BWD: the GEMM result is dz (M, L), stats (M, 2L) in, C = dstats (M, 2L) out, kscale = beta / B
+  const float* eps; float* z; const float* stats; float kscale; int msep;   // column sums riding along: out[j] = sum_i src[i*cs_N + j] (bias gradient)
   int M, N, K;
   long long sai, sak, sbk, sbj;
   int ldc, epi, act;
@@ -274,6 +277,58 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const GemmArgs g) {
   }
 }
 
+// Reparameterisation (/root/reference/models/autoencoders.py:169-176) in the epilogue of the encoder fc's split-K
+// reduction: a thread sums the adjacent columns (2l, 2l+1) = (mu, log_var), writes them to `stats` and
+// z = mu + exp(log_var / 2) * eps next to them.
+__global__ __launch_bounds__(256) void gemm_splitk_reparam_fwd_kernel(const GemmArgs g, int splits) {
+  const size_t total = (size_t)g.M * g.N, pairs = total / 2;
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < pairs; p += (size_t)gridDim.x * 256) {
+    float2 v = make_float2(0.f, 0.f);
+    for (int zz = 0; zz < splits; ++zz) {
+      const float2 t = *(const float2*)(g.slab + (size_t)zz * total + 2 * p);
+      v.x += t.x; v.y += t.y;
+    }
+    const int j = (int)((2 * p) % g.N);
+    if (g.bias) { v.x += g.bias[j]; v.y += g.bias[j + 1]; }
+    *(float2*)(g.C + 2 * p) = v;
+    g.z[p] = v.x + expf(0.5f * v.y) * g.eps[p];
+  }
+}
+// ... and its backward, with the KL (or --mse prior) gradient of /root/reference/main.py:39-45, in the epilogue of the
+// decoder fc's dgrad reduction: dz = sum of the slabs;
+//   dstats[.,0] = dz + kscale * dKL/dmu,  dstats[.,1] = dz * eps * sigma / 2 + kscale * dKL/dlog_var   (kscale = beta / B)
+__device__ __forceinline__ float2 gmk_reparam_bwd_pair(float dz, float2 st, float eps, float kscale, int msep) {
+  const float sg = expf(0.5f * st.y);
+  float2 d;
+  d.x = dz;
+  d.y = dz * eps * 0.5f * sg;
+  if (msep) { d.x += kscale * 2.f * st.x; d.y += kscale * (sg - 1.f) * sg; }
+  else { d.x += kscale * st.x; d.y += kscale * 0.5f * (expf(st.y) - 1.f); }
+  return d;
+}
+__global__ __launch_bounds__(256) void gemm_splitk_reparam_bwd_kernel(const GemmArgs g, int splits) {
+  const size_t total = (size_t)g.M * g.N;
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (size_t)gridDim.x * 256) {
+    float dz = 0.f;
+    for (int zz = 0; zz < splits; ++zz) dz += g.slab[(size_t)zz * total + p];
+    const float2 st = *(const float2*)(g.stats + 2 * p);
+    *(float2*)(g.C + 2 * p) = gmk_reparam_bwd_pair(dz, st, g.eps[p], g.kscale, g.msep);
+  }
+}
+// unsplit fallbacks (shapes whose GEMM needs no split: not the VAE's): elementwise passes over the GEMM's plain output
+__global__ __launch_bounds__(256) void reparam_fwd_from_stats_kernel(const GemmArgs g) {
+  const size_t pairs = (size_t)g.M * g.N / 2;
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < pairs; p += (size_t)gridDim.x * 256) {
+    const float2 v = *(const float2*)(g.C + 2 * p);
+    g.z[p] = v.x + expf(0.5f * v.y) * g.eps[p];
+  }
+}
+__global__ __launch_bounds__(256) void reparam_bwd_from_dz_kernel(const GemmArgs g, const float* dz) {
+  const size_t total = (size_t)g.M * g.N;
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (size_t)gridDim.x * 256)
+    *(float2*)(g.C + 2 * p) = gmk_reparam_bwd_pair(dz[p], *(const float2*)(g.stats + 2 * p), g.eps[p], g.kscale, g.msep);
+}
+
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs g, int splits) {
   const size_t total = (size_t)g.M * g.N;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
@@ -321,10 +376,18 @@ extern "C" size_t gmk_linear_workspace_bytes(int M, int K, int N) {
 
 static int run_gemm(GemmArgs g, void* ws, size_t ws_bytes, hipStream_t s) {
   const int splits = pick_splits(g.M, g.N, g.K);
+  const int fused = g.epi;   // GEPI_REPARAM_*: applied by the reduce kernel (or a fallback pass), never by the GEMM itself
+  float* const fused_out = g.C;
+  if (fused == GEPI_REPARAM_FWD) { g.epi = GEPI_BIAS_ACT; g.act = GMK_ACT_NONE; g.dact = nullptr; }
+  if (fused == GEPI_REPARAM_BWD) g.epi = GEPI_NONE;
   int kper = (g.K + splits - 1) / splits;
   kper = (kper + GK - 1) / GK * GK;
   g.kper = kper;
   const int zs = (g.K + kper - 1) / kper;
+  if (fused == GEPI_REPARAM_BWD && zs == 1) {   // unsplit: the GEMM writes dz to the workspace, a second pass finishes
+    if (!ws || ws_bytes < sizeof(float) * (size_t)g.M * g.N) return GMK_E_WORKSPACE;
+    g.C = (float*)ws;
+  }
   dim3 grid((g.N + GT - 1) / GT, (g.M + GT - 1) / GT, zs);
   const bool want_cs = g.cs_src != nullptr;
   if (zs > 1) {
@@ -351,7 +414,16 @@ static int run_gemm(GemmArgs g, void* ws, size_t ws_bytes, hipStream_t s) {
   if (zs > 1) {
     size_t total = (size_t)g.M * g.N;
     int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, g, zs);
+    if (fused == GEPI_REPARAM_FWD) hipLaunchKernelGGL(gemm_splitk_reparam_fwd_kernel, dim3(blocks), dim3(256), 0, s, g, zs);
+    else if (fused == GEPI_REPARAM_BWD) { g.C = fused_out; hipLaunchKernelGGL(gemm_splitk_reparam_bwd_kernel, dim3(blocks), dim3(256), 0, s, g, zs); }
+    else hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, g, zs);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  } else if (fused == GEPI_REPARAM_FWD || fused == GEPI_REPARAM_BWD) {
+    size_t total = (size_t)g.M * g.N;
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+    if (fused == GEPI_REPARAM_FWD) hipLaunchKernelGGL(reparam_fwd_from_stats_kernel, dim3(blocks), dim3(256), 0, s, g);
+    else { const float* dz = g.C; g.C = fused_out; hipLaunchKernelGGL(reparam_bwd_from_dz_kernel, dim3(blocks), dim3(256), 0, s, g, dz); }
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
@@ -395,5 +467,32 @@ extern "C" int gmk_linear_wgrad(const float* dy, const float* x, float* dw, floa
   g.M = N; g.N = K; g.K = M; g.sai = 1; g.sak = N; g.sbk = K; g.sbj = 1; g.ldc = K;
   g.epi = GEPI_NONE; g.act = 0;
   if (dbias) { g.cs_src = dy; g.cs_out = dbias; g.cs_M = M; g.cs_N = N; }
+  return run_gemm(g, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// nn.Linear forward of the VAE encoder head fused with the reparameterisation (the bias add and z = mu + sigma * eps
+// run in the epilogue of the split-K reduction): stats (M, 2L) and z (M, L) out.  N = 2L.
+extern "C" int gmk_linear_fwd_reparam(const float* x, const float* w, const float* bias, const float* eps, float* stats,
+                                      float* z, int M, int K, int N, void* ws, size_t ws_bytes, gmk_stream_t stream) {
+  GMK_REQUIRE(x && w && eps && stats && z, GMK_E_NULL);
+  GMK_REQUIRE(M > 0 && K > 0 && N > 0 && N % 2 == 0, GMK_E_SHAPE);
+  GemmArgs g{};
+  g.A = x; g.B = w; g.C = stats; g.bias = bias;
+  g.M = M; g.N = N; g.K = K; g.sai = K; g.sak = 1; g.sbk = 1; g.sbj = K; g.ldc = N;
+  g.epi = GEPI_REPARAM_FWD; g.eps = eps; g.z = z;
+  return run_gemm(g, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// Backward of the decoder's nn.Linear input (dz = dy @ w) fused with the backward of the reparameterisation and the
+// gradient of beta * KL (or of the --mse prior): dstats (M, K, 2) out, K = latent size.  kl_scale = beta / batch.
+extern "C" int gmk_linear_dgrad_reparam(const float* dy, const float* w, const float* stats, const float* eps,
+                                        float* dstats, int M, int K, int N, float kl_scale, int mse_prior, void* ws,
+                                        size_t ws_bytes, gmk_stream_t stream) {
+  GMK_REQUIRE(dy && w && stats && eps && dstats, GMK_E_NULL);
+  GMK_REQUIRE(M > 0 && K > 0 && N > 0, GMK_E_SHAPE);
+  GemmArgs g{};
+  g.A = dy; g.B = w; g.C = dstats;
+  g.M = M; g.N = K; g.K = N; g.sai = N; g.sak = 1; g.sbk = K; g.sbj = 1; g.ldc = K;
+  g.epi = GEPI_REPARAM_BWD; g.eps = eps; g.stats = stats; g.kscale = kl_scale; g.msep = mse_prior ? 1 : 0;
   return run_gemm(g, ws, ws_bytes, (hipStream_t)stream);
 }

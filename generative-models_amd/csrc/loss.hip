@@ -10,6 +10,44 @@
 
 extern "C" size_t gmk_vae_loss_workspace_bytes(void) { return sizeof(double) * 4 * LOSS_BLOCKS; }
 
+// Fixed-order sum of the block partials -> losses.  inv_bl > 0 selects the eval form: losses[3] = mean |mu|,
+// losses[4] = mean sigma (over B*L elements).  One 256-thread block.  The partials are read with agent-scope loads
+// (sc1: they bypass this CU's L1), which is what the in-kernel hand-off of the one-launch form needs and costs the
+// separate finalize kernel nothing.
+struct LossFin { float* losses; double inv_n, inv_b, inv_bl; float beta; int variational; unsigned* counter; };
+__device__ __forceinline__ double gmk_ld_agent(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void vae_loss_finalize_block(const double* partial, int nblocks, const LossFin f, double (*red)[4]) {
+  double a = 0, b = 0, c = 0, d = 0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) {
+    a += gmk_ld_agent(partial + i); b += gmk_ld_agent(partial + LOSS_BLOCKS + i);
+    if (f.inv_bl > 0) { c += gmk_ld_agent(partial + 2 * LOSS_BLOCKS + i); d += gmk_ld_agent(partial + 3 * LOSS_BLOCKS + i); }
+  }
+  a = gmk_wave_sum(a); b = gmk_wave_sum(b); c = gmk_wave_sum(c); d = gmk_wave_sum(d);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; red[2][threadIdx.x >> 6] = c; red[3][threadIdx.x >> 6] = d;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sa = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    double sb = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    float rec = (float)(sa * f.inv_n);
+    float kl = f.variational ? (float)(sb * f.inv_b) : 0.f;
+    f.losses[0] = rec;
+    f.losses[1] = kl;
+    f.losses[2] = f.variational ? rec + f.beta * kl : rec;
+    if (f.inv_bl > 0) {
+      f.losses[3] = f.variational ? (float)((red[2][0] + red[2][1] + red[2][2] + red[2][3]) * f.inv_bl) : 0.f;
+      f.losses[4] = f.variational ? (float)((red[3][0] + red[3][1] + red[3][2] + red[3][3]) * f.inv_bl) : 0.f;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void vae_loss_finalize_kernel(const double* __restrict__ partial, int nblocks, const LossFin f) {
+  __shared__ double red[4][4];
+  vae_loss_finalize_block(partial, nblocks, f, red);
+}
+
 // GRAD = false is the no-grad form of compute_test_loss (main.py:73-111): no gradient stores, and two more sums
 // (|mu| and sigma = exp(log_var / 2), main.py:101-102) ride along with the KL pass.
 template <bool SIGMOID, bool WRITE_RECON, bool GRAD>
@@ -17,7 +55,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void vae_loss_kernel(
     const float4* __restrict__ pre, const float4* __restrict__ image, const float2* __restrict__ stats,
     float4* __restrict__ recon_out, float4* __restrict__ dpre, float2* __restrict__ dstats,
     double* __restrict__ partial, int64_t n4, int64_t nstat, float gscale /* 2/(B*chw) */,
-    float kscale /* beta/B */, int mse_prior) {
+    float kscale /* beta/B */, int mse_prior, const LossFin fin /* fin.counter != NULL: one-launch form */) {
   const int64_t gtid = (int64_t)blockIdx.x * LOSS_THREADS + threadIdx.x;
   const int64_t gstride = (int64_t)gridDim.x * LOSS_THREADS;
   float se = 0.f;  // sum of squared errors (this thread: at most a few float4)
@@ -56,7 +94,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void vae_loss_kernel(
       g.y = kscale * 0.5f * (e - 1.f);
       if (!GRAD) sig += expf(0.5f * s.y);
     }
-    if (GRAD) dstats[i] = g;
+    if (GRAD) { if (dstats) dstats[i] = g; }   // dstats == NULL: the KL gradient is applied elsewhere (GMK_LOSS_NO_DSTATS)
     else amu += fabsf(s.x);
   }
   __shared__ double red[4][LOSS_THREADS / 64];
@@ -66,57 +104,59 @@ __global__ __launch_bounds__(LOSS_THREADS) void vae_loss_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) { red[0][wave] = a; red[1][wave] = b; red[2][wave] = c; red[3][wave] = d; }
   __syncthreads();
+  if (fin.counter == nullptr) {
+    if (threadIdx.x == 0) {
+      double sa = 0, sb = 0, sc = 0, sd = 0;
+      for (int w = 0; w < LOSS_THREADS / 64; ++w) { sa += red[0][w]; sb += red[1][w]; sc += red[2][w]; sd += red[3][w]; }
+      partial[blockIdx.x] = sa;
+      partial[LOSS_BLOCKS + blockIdx.x] = sb;
+      if (!GRAD) { partial[2 * LOSS_BLOCKS + blockIdx.x] = sc; partial[3 * LOSS_BLOCKS + blockIdx.x] = sd; }
+    }
+    return;
+  }
+  // One-launch form: the block whose arrival ticket is the last one sums the partials (fixed order, same code as the
+  // finalize kernel).  Hand-off per MI355X_MICROARCH.md (inter-workgroup visibility): ONE lane per block stores the
+  // block's partials with agent-scope (sc1, write-through) stores, drains them (vmcnt(0)), then takes a ticket with a
+  // returning agent-scope atomic add; the last block runs an agent-scope acquire (invalidates its CU's L1), waits for
+  // it, and only then, behind a workgroup barrier, do its waves load the partials (sc1 loads).  The counter is reset
+  // for the next launch by that block.
+  __shared__ int is_last;
   if (threadIdx.x == 0) {
     double sa = 0, sb = 0, sc = 0, sd = 0;
     for (int w = 0; w < LOSS_THREADS / 64; ++w) { sa += red[0][w]; sb += red[1][w]; sc += red[2][w]; sd += red[3][w]; }
-    partial[blockIdx.x] = sa;
-    partial[LOSS_BLOCKS + blockIdx.x] = sb;
-    if (!GRAD) { partial[2 * LOSS_BLOCKS + blockIdx.x] = sc; partial[3 * LOSS_BLOCKS + blockIdx.x] = sd; }
-  }
-}
-
-// inv_bl > 0 selects the eval form: losses[3] = mean |mu|, losses[4] = mean sigma (over B*L elements)
-__global__ __launch_bounds__(256) void vae_loss_finalize_kernel(const double* __restrict__ partial, int nblocks,
-                                                                float* __restrict__ losses, double inv_n,
-                                                                double inv_b, float beta, int variational,
-                                                                double inv_bl) {
-  __shared__ double red[4][4];
-  double a = 0, b = 0, c = 0, d = 0;
-  for (int i = threadIdx.x; i < nblocks; i += 256) {
-    a += partial[i]; b += partial[LOSS_BLOCKS + i];
-    if (inv_bl > 0) { c += partial[2 * LOSS_BLOCKS + i]; d += partial[3 * LOSS_BLOCKS + i]; }
-  }
-  a = gmk_wave_sum(a); b = gmk_wave_sum(b); c = gmk_wave_sum(c); d = gmk_wave_sum(d);
-  if ((threadIdx.x & 63) == 0) {
-    red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; red[2][threadIdx.x >> 6] = c; red[3][threadIdx.x >> 6] = d;
+    __hip_atomic_store(partial + blockIdx.x, sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(partial + LOSS_BLOCKS + blockIdx.x, sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!GRAD) {
+      __hip_atomic_store(partial + 2 * LOSS_BLOCKS + blockIdx.x, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(partial + 3 * LOSS_BLOCKS + blockIdx.x, sd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = ticket == gridDim.x - 1;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    is_last = last;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double sa = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    double sb = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    float rec = (float)(sa * inv_n);
-    float kl = variational ? (float)(sb * inv_b) : 0.f;
-    losses[0] = rec;
-    losses[1] = kl;
-    losses[2] = variational ? rec + beta * kl : rec;
-    if (inv_bl > 0) {
-      losses[3] = variational ? (float)((red[2][0] + red[2][1] + red[2][2] + red[2][3]) * inv_bl) : 0.f;
-      losses[4] = variational ? (float)((red[3][0] + red[3][1] + red[3][2] + red[3][3]) * inv_bl) : 0.f;
-    }
-  }
+  if (!is_last) return;
+  vae_loss_finalize_block(partial, (int)gridDim.x, fin, (double(*)[4])red);
+  if (threadIdx.x == 0) __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // shared by gmk_vae_loss_fwd_bwd (grad = true) and gmk_vae_loss_eval (grad = false; `losses` then has 5 floats)
 static int vae_loss_launch(const float* pre, const float* image, const float* stats, float* recon_out, float* dpre,
                            float* dstats, float* losses, int64_t B, int64_t chw, int64_t L, float beta, int flags,
-                           void* ws, size_t ws_bytes, gmk_stream_t stream, bool grad) {
+                           void* ws, size_t ws_bytes, gmk_stream_t stream, bool grad, unsigned* counter = nullptr) {
   GMK_REQUIRE(pre && image && losses && ws, GMK_E_NULL);
   GMK_REQUIRE(!grad || dpre, GMK_E_NULL);
   GMK_REQUIRE(B > 0 && chw > 0 && (B * chw) % 4 == 0, GMK_E_SHAPE);
   GMK_REQUIRE(ws_bytes >= gmk_vae_loss_workspace_bytes(), GMK_E_WORKSPACE);
   GMK_REQUIRE(gmk_aligned16(pre) && gmk_aligned16(image) && gmk_aligned16(dpre) && gmk_aligned16(ws), GMK_E_ALIGN);
   const bool variational = stats != nullptr;
-  if (variational) GMK_REQUIRE((dstats || !grad) && L > 0, GMK_E_NULL);
+  if (variational) GMK_REQUIRE((dstats || !grad || (flags & GMK_LOSS_NO_DSTATS)) && L > 0, GMK_E_NULL);
+  if (flags & GMK_LOSS_NO_DSTATS) dstats = nullptr;
   if (recon_out) GMK_REQUIRE(gmk_aligned16(recon_out), GMK_E_ALIGN);
   hipStream_t s = (hipStream_t)stream;
   const int64_t n4 = B * chw / 4, nstat = variational ? B * L : 0;
@@ -127,10 +167,12 @@ static int vae_loss_launch(const float* pre, const float* image, const float* st
   double* partial = (double*)ws;
   const bool sig = flags & GMK_LOSS_SIGMOID;
   const int msep = (flags & GMK_LOSS_MSE_PRIOR) ? 1 : 0;
+  LossFin fin{losses, 1.0 / ((double)B * (double)chw), 1.0 / (double)B,
+              grad ? 0.0 : 1.0 / ((double)B * (double)(L > 0 ? L : 1)), beta, variational ? 1 : 0, counter};
 #define LAUNCH(S, R, G)                                                                                      \
   hipLaunchKernelGGL((vae_loss_kernel<S, R, G>), dim3(nblocks), dim3(LOSS_THREADS), 0, s, (const float4*)pre, \
                      (const float4*)image, (const float2*)stats, (float4*)recon_out, (float4*)dpre,          \
-                     (float2*)dstats, partial, n4, nstat, gscale, kscale, msep)
+                     (float2*)dstats, partial, n4, nstat, gscale, kscale, msep, fin)
   if (grad) {
     if (sig) { if (recon_out) LAUNCH(true, true, true); else LAUNCH(true, false, true); }
     else     { if (recon_out) LAUNCH(false, true, true); else LAUNCH(false, false, true); }
@@ -140,9 +182,8 @@ static int vae_loss_launch(const float* pre, const float* image, const float* st
   }
 #undef LAUNCH
   GMK_CHECK_LAUNCH();
-  hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, s, partial, nblocks, losses,
-                     1.0 / ((double)B * (double)chw), 1.0 / (double)B, beta, variational ? 1 : 0,
-                     grad ? 0.0 : 1.0 / ((double)B * (double)(L > 0 ? L : 1)));
+  if (counter) return GMK_OK;   // one-launch form: the last block has finalized
+  hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, s, partial, nblocks, fin);
   GMK_CHECK_LAUNCH();
   return GMK_OK;
 }
@@ -152,6 +193,18 @@ extern "C" int gmk_vae_loss_fwd_bwd(const float* pre, const float* image, const 
                                     float beta, int flags, void* ws, size_t ws_bytes, gmk_stream_t stream) {
   return vae_loss_launch(pre, image, stats, recon_out, dpre, dstats, losses, B, chw, L, beta, flags, ws, ws_bytes,
                          stream, true);
+}
+
+// One launch: `sync` = 256 bytes of device memory, zero before the first call and owned by this entry point (the kernel
+// leaves it zero); the last block to finish sums the partials.  Calls sharing a `sync` must be stream-ordered.
+extern "C" int gmk_vae_loss_fwd_bwd_fused(const float* pre, const float* image, const float* stats, float* recon_out,
+                                          float* dpre, float* dstats, float* losses, int64_t B, int64_t chw, int64_t L,
+                                          float beta, int flags, void* ws, size_t ws_bytes, void* sync,
+                                          gmk_stream_t stream) {
+  GMK_REQUIRE(sync, GMK_E_NULL);
+  GMK_REQUIRE((((uintptr_t)sync) & 255u) == 0, GMK_E_ALIGN);
+  return vae_loss_launch(pre, image, stats, recon_out, dpre, dstats, losses, B, chw, L, beta, flags, ws, ws_bytes,
+                         stream, true, (unsigned*)sync);
 }
 
 extern "C" int gmk_vae_loss_eval(const float* pre, const float* image, const float* stats, float* recon_out,

@@ -32,6 +32,8 @@ SIGNATURES = {
     "gmk_linear_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
     "gmk_linear_dgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _Z, _P]),
     "gmk_linear_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _Z, _P]),
+    "gmk_linear_fwd_reparam": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _Z, _P]),
+    "gmk_linear_dgrad_reparam": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _Z, _P]),
     "gmk_reparam_fwd": (_I, [_P, _P, _P, _L, _L, _P]),
     "gmk_reparam_bwd": (_I, [_P, _P, _P, _P, _L, _L, _I, _P]),
     "gmk_maxpool2_fwd": (_I, [_P, _P, _P, _L, _I, _I, _P]),
@@ -49,6 +51,7 @@ SIGNATURES = {
     "gmk_vae_loss_workspace_bytes": (_Z, []),
     "gmk_vae_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _F, _I, _P, _Z, _P]),
     "gmk_vae_loss_fwd_bwd_static": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _F, _I, _P]),
+    "gmk_vae_loss_fwd_bwd_fused": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _F, _I, _P, _Z, _P, _P]),
     "gmk_vae_loss_eval": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _F, _I, _P, _Z, _P]),
 }
 

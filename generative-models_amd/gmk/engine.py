@@ -29,8 +29,10 @@ def _o(gout, name):
 
 
 # ------------------------------------------------------------------------------ encoder
-def encoder_forward(p, x, *, act, no_pool, ksize, train):
-    """Returns (out (B, mult*L), saved).  x: (B,3,H,W) contiguous fp32 CUDA."""
+def encoder_forward(p, x, *, act, no_pool, ksize, train, reparam_eps=None):
+    """Returns (out (B, mult*L), saved).  x: (B,3,H,W) contiguous fp32 CUDA.
+    reparam_eps (B, L): VAE head fused with the reparameterisation (gmk_linear_fwd_reparam): out is then the
+    interleaved stats (B, L, 2) and saved["z"] the latent z = mu + sigma * eps."""
     sv = {"x": x}
     conv = ops.conv2d_fwd
 
@@ -55,7 +57,10 @@ def encoder_forward(p, x, *, act, no_pool, ksize, train):
     a5, d5 = cv(a4, "conv3", 1)
     B = x.shape[0]
     flat = a5.view(B, -1)
-    out = ops.linear_fwd(flat, p["fc.weight"], p["fc.bias"])
+    if reparam_eps is not None:
+        out, sv["z"] = ops.linear_fwd_reparam(flat, p["fc.weight"], p["fc.bias"], reparam_eps)
+    else:
+        out = ops.linear_fwd(flat, p["fc.weight"], p["fc.bias"])
     if train:
         sv.update(a1=a1, d1=d1, a2=a2, d2=d2, i1=i1, a3=a3, d3=d3, a4=a4, d4=d4, i2=i2, a5=a5, d5=d5)
     return out, sv
@@ -131,8 +136,10 @@ def decoder_forward(p, z, *, act, num_channels, no_upsample, interpolation, ksiz
     return out, sv
 
 
-def decoder_backward(p, sv, dpre, *, no_upsample, interpolation, ksize, need_dz=True, gout=None, side=None):
-    """dpre: gradient w.r.t. conv3's pre-activation output (B,3,H,W).  Returns (param grads, dz)."""
+def decoder_backward(p, sv, dpre, *, no_upsample, interpolation, ksize, need_dz=True, gout=None, side=None, reparam=None):
+    """dpre: gradient w.r.t. conv3's pre-activation output (B,3,H,W).  Returns (param grads, dz).
+    reparam = (stats, eps, kl_scale, mse_prior): the fc dgrad is fused with the reparameterisation backward and the
+    beta*KL gradient (gmk_linear_dgrad_reparam) and the second return value is dstats (B, L, 2) instead of dz."""
     g = {}
     B = dpre.shape[0]
     g["conv3.weight"], g["conv3.bias"] = _wg(side, lambda: ops.conv2d_wgrad(dpre, sv["h4"], ksize, 1, out=_o(gout, "conv3")), dpre)
@@ -155,5 +162,8 @@ def decoder_backward(p, sv, dpre, *, no_upsample, interpolation, ksize, need_dz=
     dz0 = ops.conv2d_dgrad(dz1, p["conv1.weight"], tuple(sv["h0v"].shape), 1, dact_in=sv["e0"].view_as(sv["h0v"]))
     dz0 = dz0.view(B, -1)
     g["fc.weight"], g["fc.bias"] = _wg(side, lambda: ops.linear_wgrad(dz0, sv["z"], out=_o(gout, "fc")), dz0)
+    if reparam is not None:
+        stats, eps, kl_scale, mse_prior = reparam
+        return g, ops.linear_dgrad_reparam(dz0, p["fc.weight"], stats, eps, kl_scale, mse_prior)
     dz = ops.linear_dgrad(dz0, p["fc.weight"]) if need_dz else None
     return g, dz

@@ -205,6 +205,30 @@ def linear_wgrad(dy, x, want_bias=True, out=None):
     return dw, db
 
 
+def linear_fwd_reparam(x, w, bias, eps):
+    """Encoder head + reparameterisation in one GEMM (+ its reduction): returns (stats (M, L, 2), z (M, L))."""
+    _chk(x, w, bias, eps)
+    M, K = x.shape
+    N = w.shape[0]
+    stats = torch.empty((M, N // 2, 2), device=x.device, dtype=torch.float32)
+    z = torch.empty((M, N // 2), device=x.device, dtype=torch.float32)
+    ws = workspace(lib().gmk_linear_workspace_bytes(M, K, N), x.device)
+    check(lib().gmk_linear_fwd_reparam(_p(x), _p(w), _p(bias), _p(eps), _p(stats), _p(z), M, K, N, _p(ws), ws.numel(), _stream()))
+    return stats, z
+
+
+def linear_dgrad_reparam(dy, w, stats, eps, kl_scale, mse_prior=False):
+    """Decoder fc dgrad + reparameterisation backward + beta*KL gradient: returns dstats (M, L, 2)."""
+    _chk(dy, w, stats, eps)
+    M, N = dy.shape
+    K = w.shape[1]
+    dstats = torch.empty_like(stats)
+    ws = workspace(lib().gmk_linear_workspace_bytes(M, K, N), dy.device)
+    check(lib().gmk_linear_dgrad_reparam(_p(dy), _p(w), _p(stats), _p(eps), _p(dstats), M, K, N, float(kl_scale),
+                                         1 if mse_prior else 0, _p(ws), ws.numel(), _stream()))
+    return dstats
+
+
 def reparam_fwd(stats, eps):
     _chk(stats, eps)
     B, L, _ = stats.shape
@@ -224,21 +248,43 @@ def reparam_bwd(dz, stats, eps, dstats=None):
     return dstats
 
 
-LOSS_SIGMOID, LOSS_MSE_PRIOR = 1, 2
+LOSS_SIGMOID, LOSS_MSE_PRIOR, LOSS_NO_DSTATS = 1, 2, 4
 
 
-def vae_loss_fwd_bwd(pre, image, stats, beta, sigmoid=True, mse_prior=False, want_recon=False):
-    """Returns (losses[3] = rec, kl, total ; dpre ; dstats or None ; recon or None)."""
+_loss_sync = {}
+
+
+def _loss_state(device):
+    """Per-device private (partials workspace, zeroed 256-byte sync word block) of the one-launch loss kernel: unlike the
+    shared byte workspace these must not be touched by any other op (the kernel keeps the sync block at zero)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _loss_sync.get(key)
+    if st is None:
+        ws = torch.empty(int(lib().gmk_vae_loss_workspace_bytes()), dtype=torch.uint8, device=device)
+        sync = torch.zeros(256, dtype=torch.uint8, device=device)
+        torch.cuda.current_stream(device).synchronize()
+        st = _loss_sync[key] = (ws, sync)
+    return st
+
+
+def vae_loss_fwd_bwd(pre, image, stats, beta, sigmoid=True, mse_prior=False, want_recon=False, want_dstats=True, fused=False):
+    """Returns (losses[3] = rec, kl, total ; dpre ; dstats or None ; recon or None).  want_dstats=False: the KL gradient
+    is left to linear_dgrad_reparam (fused train step)."""
     _chk(pre, image, stats)
     B = pre.shape[0]
     chw = pre.numel() // B
     L = 0 if stats is None else stats.shape[1]
     dpre = torch.empty_like(pre)
-    dstats = None if stats is None else torch.empty_like(stats)
+    dstats = None if (stats is None or not want_dstats) else torch.empty_like(stats)
     recon = torch.empty_like(pre) if want_recon else None
     losses = torch.empty(3, device=pre.device, dtype=torch.float32)
     ws = workspace(lib().gmk_vae_loss_workspace_bytes(), pre.device)
-    flags = (LOSS_SIGMOID if sigmoid else 0) | (LOSS_MSE_PRIOR if mse_prior else 0)
+    flags = (LOSS_SIGMOID if sigmoid else 0) | (LOSS_MSE_PRIOR if mse_prior else 0) | (0 if want_dstats else LOSS_NO_DSTATS)
+    if fused:   # one launch (the last block finalizes); private workspace + sync block, main-stream callers only
+        lws, sync = _loss_state(pre.device)
+        check(lib().gmk_vae_loss_fwd_bwd_fused(_p(pre), _p(image), _p(stats), _p(recon), _p(dpre), _p(dstats), _p(losses),
+                                               B, chw, L, float(beta), flags, _p(lws), lws.numel(), _p(sync), _stream()))
+        return losses, dpre, dstats, recon
     check(lib().gmk_vae_loss_fwd_bwd(_p(pre), _p(image), _p(stats), _p(recon), _p(dpre), _p(dstats), _p(losses),
                                      B, chw, L, float(beta), flags, _p(ws), ws.numel(), _stream()))
     return losses, dpre, dstats, recon

@@ -244,14 +244,14 @@ class Autoencoder(nn.Module):
         the reference runs the full model and discards the reconstruction, metrics.py:70-73)."""
         enc = self.encoder
         pe = {n: p.data for n, p in enc.named_parameters()}
-        out, _ = engine.encoder_forward(pe, x.contiguous(), act=enc._act_id, no_pool=enc.no_pool,
-                                        ksize=enc.kernel_size, train=False)
         if self.variational:
-            self.stats = out.view(x.shape[0], self.latent_size, 2)
             self.normal = torch.randn((x.shape[0], self.latent_size), device=x.device, dtype=torch.float32)
-            self.latent_vector = ops.reparam_fwd(self.stats, self.normal)
+            self.stats, sv = engine.encoder_forward(pe, x.contiguous(), act=enc._act_id, no_pool=enc.no_pool,
+                                                    ksize=enc.kernel_size, train=False, reparam_eps=self.normal)
+            self.latent_vector = sv["z"]
         else:
-            self.latent_vector = out
+            self.latent_vector, _ = engine.encoder_forward(pe, x.contiguous(), act=enc._act_id, no_pool=enc.no_pool,
+                                                           ksize=enc.kernel_size, train=False)
         return self.latent_vector
 
     @torch.no_grad()
@@ -265,15 +265,17 @@ class Autoencoder(nn.Module):
         pd = {n: p.data for n, p in dec.named_parameters()}
         image = image.contiguous()
         B = image.shape[0]
-        out, _ = engine.encoder_forward(pe, image, act=enc._act_id, no_pool=enc.no_pool, ksize=enc.kernel_size, train=False)
         if self.variational:
-            stats = out.view(B, self.latent_size, 2)
             if eps is None:
                 eps = torch.randn((B, self.latent_size), device=image.device, dtype=torch.float32)
-            z = ops.reparam_fwd(stats, eps)
+            eps = eps.contiguous()
+            stats, sv = engine.encoder_forward(pe, image, act=enc._act_id, no_pool=enc.no_pool, ksize=enc.kernel_size,
+                                               train=False, reparam_eps=eps)
+            z = sv["z"]
             self.stats, self.normal = stats, eps
         else:
-            stats, z = None, out
+            z, _ = engine.encoder_forward(pe, image, act=enc._act_id, no_pool=enc.no_pool, ksize=enc.kernel_size, train=False)
+            stats = None
         self.latent_vector = z
         pre, _ = engine.decoder_forward(pd, z, act=dec._act_id, num_channels=dec.num_channels,
                                         no_upsample=dec.no_upsample, interpolation=dec._interp,
@@ -302,20 +304,26 @@ class Autoencoder(nn.Module):
         gd = {n: p.grad for n, p in dec.named_parameters()}
         image = image.contiguous()
         B = image.shape[0]
-        out, sve = engine.encoder_forward(pe, image, act=enc._act_id, no_pool=enc.no_pool, ksize=enc.kernel_size, train=True)
         if self.variational:
-            stats = out.view(B, self.latent_size, 2)
             if eps is None:
                 eps = torch.randn((B, self.latent_size), device=image.device, dtype=torch.float32)
-            z = ops.reparam_fwd(stats, eps)
+            eps = eps.contiguous()
+            # encoder head + reparameterisation: one GEMM whose reduction epilogue writes stats and z
+            stats, sve = engine.encoder_forward(pe, image, act=enc._act_id, no_pool=enc.no_pool, ksize=enc.kernel_size,
+                                                train=True, reparam_eps=eps)
+            z = sve["z"]
             self.stats, self.normal = stats, eps
         else:
+            out, sve = engine.encoder_forward(pe, image, act=enc._act_id, no_pool=enc.no_pool, ksize=enc.kernel_size, train=True)
             stats, z = None, out
         self.latent_vector = z
         pre, svd = engine.decoder_forward(pd, z, act=dec._act_id, num_channels=dec.num_channels,
                                           no_upsample=dec.no_upsample, interpolation=dec._interp,
                                           ksize=dec.kernel_size, base=dec.base, train=True, final_act=None)
-        losses, dpre, dstats, _ = ops.vae_loss_fwd_bwd(pre, image, stats, beta, sigmoid=sigmoid, mse_prior=mse_prior)
+        # sigmoid + MSE + beta*KL and d/d pre in one pass; the KL gradient rides with the reparameterisation backward in
+        # the decoder fc's dgrad epilogue below, so no dstats round trip and no separate reparam launches
+        losses, dpre, _, _ = ops.vae_loss_fwd_bwd(pre, image, stats, beta, sigmoid=sigmoid, mse_prior=mse_prior,
+                                                  want_dstats=False, fused=True)
         # weight gradients run on a side stream, overlapping the dgrad chain on this one (gmk.ops.SideQueue)
         side = ops.side_queue(image.device)
 
@@ -329,13 +337,11 @@ class Autoencoder(nn.Module):
                 with torch.cuda.stream(side.stream):
                     reducer.ready(name)
 
+        rp = (stats, eps, float(beta) / B, mse_prior) if self.variational else None
         _, dz = engine.decoder_backward(pd, svd, dpre, no_upsample=dec.no_upsample, interpolation=dec._interp,
-                                        ksize=dec.kernel_size, need_dz=True, gout=gd, side=side)
+                                        ksize=dec.kernel_size, need_dz=True, gout=gd, side=side, reparam=rp)
         bucket_ready("decoder")
-        if self.variational:
-            dout = ops.reparam_bwd(dz, stats, eps, dstats=dstats).view(B, -1)
-        else:
-            dout = dz
+        dout = dz.view(B, -1)
         engine.encoder_backward(pe, sve, dout, no_pool=enc.no_pool, ksize=enc.kernel_size, gout=ge,
                                 on_fc_done=lambda: bucket_ready("encoder.fc"), side=side)
         bucket_ready("encoder.conv")

@@ -104,6 +104,22 @@ int gmk_linear_dgrad(const float* dy, const float* w, const float* dact_in, floa
 int gmk_linear_wgrad(const float* dy, const float* x, float* dw, float* dbias,
                      int M, int K, int N, void* ws, size_t ws_bytes, gmk_stream_t stream);
 
+/* The VAE head and tail fused into the two fully connected layers next to the latent (what north_star calls the fused
+ * tail; /root/reference/models/autoencoders.py:57-61,169-176 and main.py:36-48):
+ * gmk_linear_fwd_reparam: stats (M, N = 2L) = x @ w^T + bias, interleaved (mu, log_var) as the reference's
+ *   view(B, L, 2), and z (M, L) = mu + exp(log_var / 2) * eps, both written by the epilogue of the GEMM's split-K
+ *   reduction (no separate reparameterisation launch).  eps (M, L).
+ * gmk_linear_dgrad_reparam: dz = dy (M, N) @ w (N, K = L) is never stored: the reduction's epilogue writes
+ *   dstats[.,.,0] = dz + kl_scale * dKL/dmu, dstats[.,.,1] = dz * eps * sigma / 2 + kl_scale * dKL/dlog_var
+ *   (kl_scale = beta / batch; the --mse prior's gradient when mse_prior != 0), i.e. autograd of the
+ *   reparameterisation plus the gradient of beta * KL; pair it with GMK_LOSS_NO_DSTATS below.
+ *   Workspaces as for gmk_linear_fwd / gmk_linear_dgrad. */
+int gmk_linear_fwd_reparam(const float* x, const float* w, const float* bias, const float* eps, float* stats,
+                           float* z, int M, int K, int N, void* ws, size_t ws_bytes, gmk_stream_t stream);
+int gmk_linear_dgrad_reparam(const float* dy, const float* w, const float* stats, const float* eps, float* dstats,
+                             int M, int K, int N, float kl_scale, int mse_prior, void* ws, size_t ws_bytes,
+                             gmk_stream_t stream);
+
 /* ---------------------------------------------------------------- VAE glue --------------
  * gmk_reparam_fwd: z[b,l] = stats[b,l,0] + exp(0.5*stats[b,l,1]) * eps[b,l]
  *   replaces models/autoencoders.py:169-176.  stats (B,L,2) interleaved mu/log_var. */
@@ -125,12 +141,22 @@ int gmk_reparam_bwd(const float* dz, const float* stats, const float* eps, float
  *   pre,image,dpre,recon_out: (B, chw) ; stats,dstats: (B,L,2) (NULL when not variational).
  *   recon_out may be NULL.  losses: 3 floats on device {rec, kl, total}.
  *   ws: >= gmk_vae_loss_workspace_bytes() bytes. */
-enum { GMK_LOSS_SIGMOID = 1, GMK_LOSS_MSE_PRIOR = 2 };
+/* GMK_LOSS_NO_DSTATS: the KL terms are summed but no dstats is written: the caller applies the KL gradient together
+ *   with the reparameterisation backward in gmk_linear_dgrad_reparam (the fused train step does). */
+enum { GMK_LOSS_SIGMOID = 1, GMK_LOSS_MSE_PRIOR = 2, GMK_LOSS_NO_DSTATS = 4 };
 size_t gmk_vae_loss_workspace_bytes(void);
 int gmk_vae_loss_fwd_bwd(const float* pre, const float* image, const float* stats,
                          float* recon_out, float* dpre, float* dstats, float* losses,
                          int64_t B, int64_t chw, int64_t L, float beta, int flags,
                          void* ws, size_t ws_bytes, gmk_stream_t stream);
+/* gmk_vae_loss_fwd_bwd_fused: the same in ONE launch (what the fused train step uses): the block that finishes last
+ *   sums the partials (same fixed order, same results).  `sync`: 256 bytes of device memory, 256-byte aligned, ZERO
+ *   before the first call and used by nothing else; the kernel leaves it zero.  Calls that share `ws` / `sync`
+ *   must be stream-ordered. */
+int gmk_vae_loss_fwd_bwd_fused(const float* pre, const float* image, const float* stats,
+                               float* recon_out, float* dpre, float* dstats, float* losses,
+                               int64_t B, int64_t chw, int64_t L, float beta, int flags,
+                               void* ws, size_t ws_bytes, void* sync, gmk_stream_t stream);
 /* gmk_vae_loss_eval: the no-grad form of the same kernel, for the eval pass of
  *   /root/reference/main.py:73-111 (compute_test_loss): no gradient stores; out5 = 5 floats on device
  *   {rec, kl, total = rec + beta*kl, mean_{b,l} |mu| (main.py:101), mean_{b,l} exp(log_var/2) (main.py:102)};

@@ -265,3 +265,53 @@ def test_upsample2(mode, shape):
     close(ops.upsample2_fwd(x.detach().float().to(dev()), mode), y, name="y")
     close(ops.upsample2_bwd(dy.to(dev()), mode, dact_in=dact.to(dev())), gx * dact.double(), name="dx")
     close(ops.upsample2_bwd(dy.to(dev()), mode), gx, name="dx(no dact)")
+
+
+# ---------------------------------------------------------------------------------------------- fused VAE tail
+@pytest.mark.parametrize("shape", [(256, 4096, 256), (8, 4096, 256), (50, 1024, 32), (4, 64, 8), (300, 96, 20)])
+def test_linear_reparam_head_and_tail(shape):
+    """gmk_linear_fwd_reparam / gmk_linear_dgrad_reparam (encoder head + reparameterisation, decoder fc dgrad +
+    reparameterisation backward + beta*KL gradient, /root/reference/models/autoencoders.py:57-61,169-176 and
+    main.py:36-48) against autograd of the oracle's formulas; split-K shapes and the unsplit fallback, both priors."""
+    from gmk import ops
+    M, K, L = shape
+    x = T(f"rx{shape}", (M, K))
+    w = T(f"rw{shape}", (2 * L, K)) / np.sqrt(K)
+    b = T(f"rb{shape}", (2 * L,))
+    eps = T(f"re{shape}", (M, L), -2, 2)
+    stats, z = ops.linear_fwd_reparam(x.to(dev()), w.to(dev()), b.to(dev()), eps.to(dev()))
+    ref = (x.double() @ w.double().T + b.double()).view(M, L, 2)
+    close(stats, ref, name="stats")
+    close(z, ref[:, :, 0] + torch.exp(0.5 * ref[:, :, 1]) * eps.double(), name="z")
+    # tail: N = decoder fc width
+    for N, msep in ((512, False), (64, True)):
+        beta = 0.37
+        st = (T(f"rs{shape}{N}", (M, L, 2)) * 0.8).double().requires_grad_(True)
+        wd = (T(f"rwd{shape}{N}", (N, L)) / np.sqrt(L)).double()
+        dy = T(f"rdy{shape}{N}", (M, N))
+        mu, lv = st[:, :, 0], st[:, :, 1]
+        zz = mu + torch.exp(0.5 * lv) * eps.double()
+        _, kl, _ = ae_oracle.train_losses(torch.zeros(1, dtype=torch.float64), torch.zeros(1, dtype=torch.float64), st, beta,
+                                          variational=True, mse_prior=msep)
+        obj = ((zz @ wd.T) * dy.double()).sum() + beta * kl      # d obj / d stats = reparam backward of dz + beta * dKL
+        (g,) = torch.autograd.grad(obj, st)
+        dstats = ops.linear_dgrad_reparam(dy.to(dev()), wd.float().to(dev()), st.detach().float().to(dev()), eps.to(dev()),
+                                          beta / M, mse_prior=msep)
+        close(dstats, g, name=f"dstats N={N} msep={msep}")
+
+
+@pytest.mark.parametrize("B,variational", [(256, True), (3, True), (1100, False)])
+def test_one_launch_loss_matches_two_launch_form(B, variational):
+    """gmk_vae_loss_fwd_bwd_fused (the last block finalizes) == gmk_vae_loss_fwd_bwd, bit for bit, on repeated calls
+    (the sync block must come back to zero each time); also with the KL gradient left out (GMK_LOSS_NO_DSTATS)."""
+    from gmk import ops
+    pre = (T(f"lp{B}", (B, 3, 32, 32)) * 3).to(dev())
+    img = T(f"li{B}", (B, 3, 32, 32), 0.0, 1.0).to(dev())
+    stats = (T(f"ls{B}", (B, 64, 2)) * 0.5).to(dev()) if variational else None
+    ref = ops.vae_loss_fwd_bwd(pre, img, stats, 0.01)
+    for rep in range(3):
+        got = ops.vae_loss_fwd_bwd(pre, img, stats, 0.01, fused=True, want_dstats=(rep != 1))
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), rep
+        if variational and rep != 1:
+            assert torch.equal(got[2], ref[2])
+        assert got[2] is None or rep != 1
