@@ -66,24 +66,65 @@ def dominant_kernel_roofline(device, iters=30):
     ach = flops / t / 1e12
     # HBM bytes per launch of this kernel/shape from the committed PMC passes (FETCH_SIZE doubled as the gfx950
     # guide prescribes, + WRITE_SIZE; tools/prof_targets.py + tools/pmc_summary.py), null if the file is absent
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
-            for row in json.load(f):
-                if row["kernel"].startswith("void conv_igemm_kernel<0, 3, 8, 1, 2, 1>") and "hbm_read_B" in row:
-                    traffic = round(row["hbm_read_B"] + row["hbm_write_B"])
-    except (OSError, ValueError, KeyError):
-        traffic = None
+    traffic = pmc_traffic("void conv_igemm_kernel<0, 3, 8, 1, 2, 1>", 131072)
     return {"kernel": "conv_igemm_kernel<S1,k3,64->64,16x16,B256>", "bound": "mfma", "achieved": round(ach, 2),
             "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
             "launch_us": round(t * 1e6, 2), "flops_per_launch": flops, "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_summary.json)"}
+            "traffic_unit": f"HBM bytes per launch (rocprofv3 PMC, profiles/{PMC_FILE})"}
+
+
+PMC_FILE = "r02_pmc_summary.json"
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
+
+
+def pmc_traffic(kernel_prefix, grid=None):
+    """HBM bytes per launch of a kernel from the committed PMC passes (FETCH_SIZE doubled as the gfx950 guide prescribes,
+    + WRITE_SIZE; tools/pmc_summary.py), None if the file or the row is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
+            for row in json.load(f):
+                if row["kernel"].startswith(kernel_prefix) and "hbm_read_B" in row and (grid is None or row.get("grid") == grid):
+                    return round(row["hbm_read_B"] + row["hbm_write_B"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def loss_kernel_roofline(device, B=65536, iters=10):
+    """north_star: achieved HBM GB/s of the fused loss kernel.  At B = 256 the kernel moves 10.5 MB (latency bound), so the
+    bandwidth figure is taken at B = 65,536 (2.68 GB): sigmoid + MSE + beta*KL forward and backward in one pass,
+    algorithmic bytes 40,960 per image (read pre + image 12,288 each, write dpre 12,288, read stats 2,048, write dstats
+    2,048), HIP events on the launch stream."""
+    from gmk import ops
+    pre = torch.randn(B, 3, 32, 32, device=device)
+    img = torch.rand(B, 3, 32, 32, device=device)
+    stats = torch.randn(B, 256, 2, device=device) * 0.1
+    for _ in range(2):
+        ops.vae_loss_fwd_bwd(pre, img, stats, 5e-6, fused=True)
+    torch.cuda.synchronize()
+    s = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(iters):
+        ops.vae_loss_fwd_bwd(pre, img, stats, 5e-6, fused=True)
+    e1.record(s)
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / iters
+    nbytes = 40960.0 * B
+    # per-launch time includes the torch.empty_like of the outputs on the host side only (asynchronous): device time
+    gbs = nbytes / t / 1e9
+    return {"kernel": f"vae_loss_kernel<sigmoid+MSE+KL fwd+bwd, B={B}>", "bound": "hbm", "achieved": round(gbs, 1),
+            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "launch_us": round(t * 1e6, 1),
+            "bytes_per_launch": nbytes, "traffic": pmc_traffic("void vae_loss_kernel<true, false, true>", B * 3072 // 4 if B * 3072 // 4 < 262144 else 262144),
+            "traffic_unit": f"HBM bytes per launch (rocprofv3 PMC, profiles/{PMC_FILE})"}
 
 
 def cpu_baseline(steps=6):
     """The oracle (CPU restatement of the reference step incl. AdamW) on this box's host cores."""
     from oracle import ae_oracle
     import torch.nn.functional as F  # noqa: F401
+    # threads actually used: the box's CPU share (OMP_NUM_THREADS is set to it there; os.cpu_count() shows the whole
+    # machine, of which this job may only use its share) -- both are reported
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
     torch.set_num_threads(cores)
     from models.autoencoders import Autoencoder
@@ -111,7 +152,7 @@ def cpu_baseline(steps=6):
     for _ in range(steps):
         step()
     dt = (time.perf_counter() - t0) / steps
-    return {"value": round(PER_GPU_BATCH / dt, 1), "unit": "images/sec", "cores": cores, "kind": "port",
+    return {"value": round(PER_GPU_BATCH / dt, 1), "unit": "images/sec", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port",
             "sample": f"{steps} train steps of batch {PER_GPU_BATCH} (oracle/ae_oracle.py, torch CPU fp32, same VAE config)",
             "ms_per_step": round(dt * 1e3, 1)}
 
@@ -188,6 +229,7 @@ def main():
             "step_mfma_frac": round(ips / world * TRAIN_MFLOP_PER_IMG * 1e6 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
         }
         out["roofline"] = dominant_kernel_roofline(device)
+        out["roofline_loss_kernel"] = loss_kernel_roofline(device)
     if not args.no_fid:
         try:
             from bench_fid import fid_stats_leg

@@ -1,0 +1,16 @@
+#!/bin/bash
+# rocprofv3 counter passes over tools/prof_targets.py (one --pmc group per run, program directly after `--`),
+# digested by tools/pmc_summary.py.  usage: tools/pmc_targets.sh <outdir-under-gpurun_out>; run on the GPU box.
+set -u
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/$1
+mkdir -p $OUT
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" \
+           "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout -s KILL 180 rocprofv3 --kernel-trace --pmc $grp -d $OUT/p$i -o p$i --output-format csv -- python3 $R/tools/prof_targets.py > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; exit 1; }
+done
+python3 $R/tools/pmc_summary.py $OUT/summary.json $(find $OUT -name "*counter_collection.csv" | sort) > $OUT/summary.txt 2>&1
+tail -n 40 $OUT/summary.txt

@@ -1,8 +1,9 @@
 """Launches the kernels BASELINE.json's north_star asks rocprof evidence for, a few times each, and nothing else:
    conv  : conv_igemm_kernel, 64->64 3x3 stride 1 at 16x16, B=256 (+gelu, +act')      -> MFMA utilisation
    loss  : vae_loss_kernel at B=256 and B=65536 (fwd+bwd in one pass)                  -> HBM bytes / GB/s
-   gram  : gram_partial_kernel, X (50000 x 256) fp32 -> fp64 moments                   -> MFMA (f64) utilisation
-   python3 tools/prof_targets.py [conv|loss|gram ...]
+   gram  : gram_partial128_kernel, X (50000 x 256) fp32 -> fp64 moments                -> MFMA (f64) utilisation, HBM bytes
+   wgrad : conv_wgrad16_kernel, the three 3x3 weight-gradient shapes of the cfg-2 step  -> MFMA utilisation
+   python3 tools/prof_targets.py [conv|loss|gram|wgrad ...]
 Used under `rocprofv3 --kernel-trace --pmc ...` (one counter group per run); tools/pmc_summary.py digests the CSVs."""
 import os
 import sys
@@ -13,7 +14,7 @@ import torch  # noqa: E402
 from gmk import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-which = sys.argv[1:] or ["conv", "loss", "gram"]
+which = sys.argv[1:] or ["conv", "loss", "gram", "wgrad"]
 REPS = 5
 if "conv" in which:
     x = torch.rand(256, 64, 16, 16, device=dev)
@@ -27,7 +28,7 @@ if "loss" in which:
         img = torch.rand(B, 3, 32, 32, device=dev)
         stats = torch.randn(B, 256, 2, device=dev) * 0.1
         for _ in range(REPS):
-            ops.vae_loss_fwd_bwd(pre, img, stats, 5e-6, sigmoid=True, mse_prior=False)
+            ops.vae_loss_fwd_bwd(pre, img, stats, 5e-6, sigmoid=True, mse_prior=False, fused=True)
         del pre, img, stats
 if "gram" in which:
     X = torch.randn(50000, 256, device=dev)
@@ -35,4 +36,10 @@ if "gram" in which:
         G = torch.zeros(256, 256, device=dev, dtype=torch.float64)
         s = torch.zeros(256, device=dev, dtype=torch.float64)
         ops.gram_accumulate(X, G, s)
+if "wgrad" in which:
+    x32, x16 = (torch.randn(256, 64, h, h, device=dev) for h in (32, 16))
+    for _ in range(REPS):
+        ops.conv2d_wgrad(x16, x16, 3, 1)
+        ops.conv2d_wgrad(x16, x32, 3, 2)
+        ops.deconv2d_wgrad(x32, x16, 3)
 torch.cuda.synchronize()
