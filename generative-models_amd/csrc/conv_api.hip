@@ -2,7 +2,7 @@
 // Every variant is one launch of conv_igemm_kernel with a different weight view / mode:
 //   conv fwd s1 -> MODE0, s2 -> MODE1 ; conv dgrad s1 -> MODE0 with flipped taps and [c][m] weights,
 //   s2 -> MODE2 ; deconv fwd -> MODE2 ; deconv dgrad -> MODE1.
-#include "conv_igemm.h"
+#include "conv_wino.h"
 #include <stdlib.h>
 
 // conv_thin_out.hip: forward of stride-1 convs with <= 8 output channels (dec.conv3)
@@ -20,6 +20,17 @@ static int conv_common_checks(int N, int Cin, int H, int W, int Cout, int ksize)
 static int dispatch(ConvGeom& g, int ksize, int mode, hipStream_t s) {
   static const int dbg = getenv("GMK_CONV_DBG") ? atoi(getenv("GMK_CONV_DBG")) : 0;  // profiling ablations only
   g.dbg = dbg;
+  // stride-1 3x3 layers whose grid fills the chip (>= GMK_WINO_MIN_BLOCKS blocks of 32 tiles x 64 channels): Winograd
+  // F(2x2,3x3) (conv_wino.h).  GMK_WINO: bit 0 = forward, bit 1 = data gradient; 0 keeps the implicit GEMM everywhere
+  static const int wino_mask = getenv("GMK_WINO") ? atoi(getenv("GMK_WINO")) : 3;
+  const int wino = wino_mask & (g.epi == 0 ? 1 : 2);
+  static const int minb = getenv("GMK_WINO_MIN_BLOCKS") ? atoi(getenv("GMK_WINO_MIN_BLOCKS")) : 256;
+  if (wino && !dbg && gmk_wino_ok(g, ksize, mode) &&
+      ((long long)g.N * g.IH * g.IW / 4 / WINO_TB) * ((g.M + WINO_MB - 1) / WINO_MB) >= minb) {
+    static const int wdbg = getenv("GMK_WINO_DBG") ? atoi(getenv("GMK_WINO_DBG")) : 0;   // profiling ablations only
+    g.dbg = wdbg;
+    return gmk_launch_conv_wino(g, s);
+  }
   return ksize == 3 ? gmk_launch_conv_k3(g, mode, s) : gmk_launch_conv_k5(g, mode, s);
 }
 

@@ -49,6 +49,13 @@ CONV_SHAPES = [
     (1, 16, 64, 64, 16, 3, 1),
     (16, 64, 16, 16, 64, 3, 1),   # enough base positions for the 64x128 tile
     (3, 24, 8, 8, 40, 3, 1),      # ragged channel counts
+    # >= 256 blocks of 32 tiles x 64 channels: forward and data gradient run the Winograd F(2x2,3x3) kernel (conv_wino.hip):
+    # the train-step shape; 2 chunks + 48 of 64 output channels; 8x8 images (2 images per block, one chunk);
+    # an odd number of chunks + two output-channel blocks, the second one ragged
+    (128, 64, 16, 16, 64, 3, 1),
+    (32, 16, 32, 32, 48, 3, 1),
+    (512, 8, 8, 8, 16, 3, 1),
+    (64, 24, 16, 16, 80, 3, 1),
     # channel counts that are not a multiple of the 8-channel K-chunk: pipelined full chunks + masked tail chunk,
     # odd / even numbers of full chunks (zero-weight padding chunk), stride 1 and 2 (dgrad runs the other modes)
     (2, 20, 16, 16, 12, 3, 1),
