@@ -43,33 +43,63 @@ def build(device):
     return model, optim, sched
 
 
-def dominant_kernel_roofline(device, iters=30):
-    """Times the heaviest kernel class of the step alone: conv_igemm_kernel on the 64->64 3x3 conv at
-    16x16 (enc.conv2 / dec.conv2 shape, B=256) with HIP events on the launch stream."""
+def _time_conv(device, stride, iters):
+    """HIP-event time per launch of the 64->64 3x3 conv forward (+GELU, +act') at B=256: 16x16 input for stride 1
+    (enc.conv2 / dec.conv2), 32x32 input for stride 2 (enc.downsample1), on the launch stream."""
     from gmk import ops
-    N, C, H = PER_GPU_BATCH, 64, 16
+    N, C, H = PER_GPU_BATCH, 64, 16 * stride
     x = torch.rand(N, C, H, H, device=device)
     w = (torch.rand(C, C, 3, 3, device=device) - 0.5) * 0.1
     b = torch.zeros(C, device=device)
     for _ in range(5):
-        ops.conv2d_fwd(x, w, b, act="gelu", want_dact=True)
+        ops.conv2d_fwd(x, w, b, stride=stride, act="gelu", want_dact=True)
     torch.cuda.synchronize()
     s = torch.cuda.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(s)
     for _ in range(iters):
-        ops.conv2d_fwd(x, w, b, act="gelu", want_dact=True)
+        ops.conv2d_fwd(x, w, b, stride=stride, act="gelu", want_dact=True)
     e1.record(s)
     torch.cuda.synchronize()
-    t = e0.elapsed_time(e1) * 1e-3 / iters
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def dominant_kernel_roofline(device, iters=30):
+    """The hot conv layer of the step (64->64 3x3 stride 1 at 16x16, B=256) timed alone.  `achieved` / `frac` are
+    ALGORITHMIC FLOPs (direct convolution: 2*Cout*Cin*9 per output pixel) over the launch time, as SURVEY 8(d)
+    defines them; since round 2 the layer runs as Winograd F(2x2,3x3) (conv_wino.hip), which executes 16/36 of those
+    multiplies on the matrix cores -- `mfma_flops_executed` / `mfma_frac_executed` state that separately."""
+    N, C, H = PER_GPU_BATCH, 64, 16
+    t = _time_conv(device, 1, iters)
     flops = 2.0 * N * H * H * C * C * 9
     ach = flops / t / 1e12
+    winograd = os.environ.get("GMK_WINO", "3") not in ("0", "2")
     # HBM bytes per launch of this kernel/shape from the committed PMC passes (FETCH_SIZE doubled as the gfx950
     # guide prescribes, + WRITE_SIZE; tools/prof_targets.py + tools/pmc_summary.py), null if the file is absent
-    traffic = pmc_traffic("void conv_igemm_kernel<0, 3, 8, 1, 2, 1>", 131072)
-    return {"kernel": "conv_igemm_kernel<S1,k3,64->64,16x16,B256>", "bound": "mfma", "achieved": round(ach, 2),
+    traffic = pmc_traffic("void conv_wino_kernel<false>" if winograd else "void conv_igemm_kernel<0, 3, 8, 1, 2, 1>", 131072)
+    out = {"kernel": ("conv_wino_kernel<fwd> (Winograd F(2x2,3x3)" if winograd else "conv_igemm_kernel<S1,k3> (implicit GEMM")
+                     + ", 64->64 3x3 s1, 16x16, B256)",
+           "bound": "mfma", "achieved": round(ach, 2),
+           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+           "launch_us": round(t * 1e6, 2), "flops_per_launch": flops, "traffic": traffic,
+           "traffic_unit": f"HBM bytes per launch (rocprofv3 PMC, profiles/{PMC_FILE})"}
+    if winograd:
+        out["mfma_flops_executed"] = flops * 16.0 / 36.0
+        out["mfma_frac_executed"] = round(ach * 16.0 / 36.0 / PEAK_F32_MFMA_TFLOPS, 4)
+    return out
+
+
+def igemm_kernel_roofline(device, iters=30):
+    """The implicit-GEMM kernel class (conv_igemm_kernel: every stride-2 / transposed conv and their data gradients,
+    the largest share of the step) on its heaviest forward shape: 64->64 3x3 stride 2, 32x32 -> 16x16, B=256."""
+    N, C, OH = PER_GPU_BATCH, 64, 16
+    t = _time_conv(device, 2, iters)
+    flops = 2.0 * N * OH * OH * C * C * 9
+    ach = flops / t / 1e12
+    return {"kernel": "conv_igemm_kernel<S2,k3,64->64,32x32->16x16,B256>", "bound": "mfma", "achieved": round(ach, 2),
             "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-            "launch_us": round(t * 1e6, 2), "flops_per_launch": flops, "traffic": traffic,
+            "launch_us": round(t * 1e6, 2), "flops_per_launch": flops,
+            "traffic": pmc_traffic("void conv_igemm_kernel<1, 3, 8, 1, 2, 4>", 131072),
             "traffic_unit": f"HBM bytes per launch (rocprofv3 PMC, profiles/{PMC_FILE})"}
 
 
@@ -229,6 +259,7 @@ def main():
             "step_mfma_frac": round(ips / world * TRAIN_MFLOP_PER_IMG * 1e6 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
         }
         out["roofline"] = dominant_kernel_roofline(device)
+        out["roofline_igemm"] = igemm_kernel_roofline(device)
         out["roofline_loss_kernel"] = loss_kernel_roofline(device)
     if not args.no_fid:
         try:
