@@ -10,7 +10,7 @@
 #define WINO_MB 64          /* output channels per block */
 #define WINO_CK 8           /* input channels per chunk */
 #define WINO_ES 130         /* LDS row stride (floats) of the epilogue transpose: even (b64 accesses), 2c mod 32 banks */
-#define WINO_RS 73          /* LDS row stride of the raw weight rows (72 floats per output channel and chunk) */
+#define WINO_RS 76          /* LDS row stride of the raw weight rows (72 floats per output channel and chunk; 16-byte rows) */
 
 static inline bool gmk_wino_ok(const ConvGeom& g, int ksize, int mode) {
   if (ksize != 3 || mode != 0) return false;

@@ -21,7 +21,7 @@
 // (+ act') or the act' multiply of dgrad on whole 512-byte channel rows.
 #include "conv_wino.h"
 
-#define WINO_LDS_FLOATS(DG) (16 * WINO_CK * 32 + 16 * WINO_CK * 64 + ((DG) ? 0 : 64 * WINO_RS))
+#define WINO_LDS_FLOATS(DG) (16 * WINO_CK * 32 + 16 * WINO_CK * 64 + ((DG) ? 0 : 64 * WINO_RS + 4))
 
 template <bool DGRAD>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvGeom g) {
@@ -54,15 +54,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvGeom g) {
       vrow[dy] = ok ? (int)((((long long)n * g.C + ci) * HW + iy * W + 2 * tx) * 4) : GMK_OOB;
     }
   }
-  // ---- weight slots: output channel mk = 16 wave + (lane & 15), channels 2cp and 2cp+1 of the chunk (cp = lane >> 4):
-  // every wave transforms the slices of its own 16 output channels ----
+  // ---- weight slots: every wave transforms the slices of its own 16 output channels; a lane takes the output channel
+  // PAIR mk, mk+1 (mk = 16 wave + 2 (lane & 7)) of channel wc = lane >> 3 of the chunk, so that each transformed value
+  // goes to LDS as one 8-byte store ----
   const int nch = g.C / CK;
-  const __amdgpu_buffer_rsrc_t rw = gmk_make_rsrc(g.w, (long long)g.w_numel * 4);
-  const int mk = 16 * wave + l15, cp = kq;
-  int wvoff[2];   // DGRAD: byte offsets of the two slices; forward: of this lane's float4 pieces (below)
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-    wvoff[j] = (m0 + mk < g.M) ? ((m0 + mk) * g.w_m_stride + (2 * cp + j) * g.w_c_stride) * 4 : GMK_OOB;
+  const int mk = 16 * wave + 2 * (lane & 7), wc = lane >> 3;
+  // DGRAD ((Cin, Cout, 3, 3)-major addressing): the pair's 18 floats are contiguous; 9 float2 loads
+  const bool wok = m0 + mk < g.M;   // (M % 16 == 0: both channels of the pair or neither)
+  const unsigned wvoff = wok ? (unsigned)(((m0 + mk) * g.w_m_stride + wc * g.w_c_stride) * 4) : 0u;
   // forward: the wave's 16 rows x 72 floats = 288 float4 pieces, piece e = lane + 64 u: row e / 18, quad e % 18
   int pvoff[5], ploff[5];
   unsigned pok = 0;
@@ -74,12 +73,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvGeom g) {
     pok |= ok ? (1u << u) : 0u;
     ploff[u] = e < 288 ? (16 * wave + row) * WINO_RS + q * 4 : 64 * WINO_RS;   // surplus lanes: 4 trash words behind the rows
   }
-  const int rraw = mk * WINO_RS + cp * 18;   // this thread's 18 raw floats in the strip
+  const int rraw = mk * WINO_RS + wc * 9;   // this lane's two 9-float slices in the strip: rows mk and mk + 1
   // ---- LDS offsets (floats) ----
-  // bank swizzle of both tiles: column ^ 16 on channels with (c ^ (c >> 1)) & 1 -- channels c, c+1 (the k-lanes of one
-  // 32-lane read pass) and c, c+2 (the two channel groups of one 32-lane weight write pass) land in different halves
+  // bank swizzle of both tiles: column ^ 16 on channels with (c ^ (c >> 1)) & 1 -- channels c and c+1 (the k-lanes of
+  // one 32-lane read pass, the two channels of one 16-lane weight write pass) land in different halves
   const int vw = ci * 32 + (ti ^ (16 * ((ci ^ (ci >> 1)) & 1)));
-  const int uw0 = (2 * cp) * 64 + (mk ^ (16 * (cp & 1))), uw1 = (2 * cp + 1) * 64 + (mk ^ (16 * ((cp & 1) ^ 1)));
+  const int uw = wc * 64 + (mk ^ (16 * ((wc ^ (wc >> 1)) & 1)));
   unsigned addrA[2], addrB;
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
@@ -99,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvGeom g) {
   // neighbouring tiles' middle columns and come from lanes -1 / +1 by DPP row shifts (tile rows are at most 16 tiles
   // long and 16-lane aligned; a shift across a tile row's end fetches a value that the column masks zero anyway).
   float xin2[2][8];
-  float wraw[2][9];   // DGRAD: the two slices, loaded directly
+  float wraw[2][9];   // the pair's two slices (DGRAD: loaded directly, flipped taps)
   f32x4 wq[5];        // forward: this lane's pieces of the wave's raw rows
   auto issue_x = [&](float* xin, int c0) {
     const int soff = c0 * HW * 4;
@@ -113,10 +112,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvGeom g) {
   auto issue_w = [&](int c0) {
     const int wsoff = c0 * g.w_c_stride * 4;
     if constexpr (DGRAD) {
+      const float2* wp = (const float2*)((const char*)g.w + (wvoff + (unsigned)wsoff));
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int t = 0; t < 9; ++t) wraw[j][t] = gmk_buffer_load(rw, wvoff[j] + (8 - t) * 4, wsoff);   // flipped taps
+      for (int q = 0; q < 9; ++q) {   // floats 2q, 2q+1 of the 18: slice (2q) / 9, tap 8 - (2q) % 9 (flipped)
+        const float2 v = wp[q];
+        wraw[(2 * q) / 9][8 - (2 * q) % 9] = wok ? v.x : 0.f;
+        wraw[(2 * q + 1) / 9][8 - (2 * q + 1) % 9] = wok ? v.y : 0.f;
+      }
     } else {
 #pragma unroll
       for (int u = 0; u < 5; ++u) wq[u] = *(const f32x4*)((const char*)g.w + (unsigned)(pvoff[u] + wsoff));
@@ -154,16 +156,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvGeom g) {
     if constexpr (!DGRAD) {   // through the wave's own strip (a wave's LDS accesses execute in order: no barrier)
 #pragma unroll
       for (int u = 0; u < 5; ++u)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) Rl[ploff[u] + k] = ((pok >> u) & 1u) ? wq[u][k] : 0.f;
+        *(float4*)(Rl + ploff[u]) = ((pok >> u) & 1u) ? make_float4(wq[u][0], wq[u][1], wq[u][2], wq[u][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wraw[j][t] = Rl[rraw + j * 9 + t];
+        for (int t = 0; t < 9; ++t) wraw[j][t] = Rl[rraw + j * WINO_RS + t];
     }
+    float uo[2][16];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      float* dst = Ul + (j ? uw1 : uw0);
       float u[4][3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -174,12 +175,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvGeom g) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float sh = 0.5f * (u[i][0] + u[i][2]);
-        dst[(4 * i + 0) * (CK * 64)] = u[i][0];
-        dst[(4 * i + 1) * (CK * 64)] = fmaf(0.5f, u[i][1], sh);
-        dst[(4 * i + 2) * (CK * 64)] = fmaf(-0.5f, u[i][1], sh);
-        dst[(4 * i + 3) * (CK * 64)] = u[i][2];
+        uo[j][4 * i + 0] = u[i][0];
+        uo[j][4 * i + 1] = fmaf(0.5f, u[i][1], sh);
+        uo[j][4 * i + 2] = fmaf(-0.5f, u[i][1], sh);
+        uo[j][4 * i + 3] = u[i][2];
       }
     }
+#pragma unroll
+    for (int x = 0; x < 16; ++x) *(float2*)(Ul + uw + x * (CK * 64)) = make_float2(uo[0][x], uo[1][x]);
   };
   // MFMA section of one chunk: step q = (k-step s, position xi), s outer so that consecutive MFMAs never share an
   // accumulator; three reads per step (tiles 0-15, tiles 16-31, couts) issued PF steps ahead
