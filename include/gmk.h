@@ -56,6 +56,9 @@ const char* gmk_strerror(int code);
 /* ---------------------------------------------------------------- convolutions ----------
  * Implicit-GEMM fp32-MFMA kernels (v_mfma_f32_32x32x2_f32), LDS-staged input patch + weights.
  * ksize in {3,5}, padding (ksize-1)/2, stride in {1,2}.
+ * Stride-1 3x3 layers with Cin % 8 == 0, Cout % 16 == 0, width <= 32 and at least 256 blocks of 128 output pixels x 64
+ * channels run as Winograd F(2x2,3x3) in fp32 (forward and data gradient; same operands, same results up to fp32
+ * rounding, ~3e-7 of the output scale); GMK_WINO=0 in the environment keeps the implicit GEMM everywhere.
  *
  * gmk_conv2d_fwd: y = act(conv2d(x, w) + bias); if dact != NULL also writes act'(pre-activation)
  *   (the backward pass multiplies by it instead of re-evaluating erf/exp).
