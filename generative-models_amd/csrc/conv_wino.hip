@@ -290,9 +290,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvGeom g) {
       }
     }
   };
-  if (g.epi != 0 || g.act == GMK_ACT_NONE) store_rows([](float z, float& a, float& d) { a = z; d = 1.f; });
-  else if (g.act == GMK_ACT_GELU) store_rows([](float z, float& a, float& d) { gmk_gelu_fwd(z, a, d); });
-  else store_rows([&](float z, float& a, float& d) { gmk_act_fwd(g.act, z, a, d); });
+  if (g.epi != 0) store_rows([](float z, float& a, float& d) { a = z; d = 1.f; });
+  else GMK_WITH_ACT(g.act, store_rows)
 }
 
 

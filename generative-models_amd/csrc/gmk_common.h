@@ -102,6 +102,17 @@ __device__ __forceinline__ void gmk_act_fwd(int act, float z, float& a, float& d
   }
 }
 
+// Epilogue helper: run `body(actf)` with actf(z, a, d) specialised for the (block-uniform) activation `act`: identity,
+// GELU (the reference default) and ReLU get straight-line code, the rest share the per-element switch (specialising all
+// seven triples the build time of the conv kernels for activations nobody benchmarks).
+#define GMK_WITH_ACT(act, body)                                                                            \
+  switch (act) {                                                                                           \
+    case GMK_ACT_GELU: body([](float z_, float& a_, float& d_) { gmk_gelu_fwd(z_, a_, d_); }); break;      \
+    case GMK_ACT_RELU: body([](float z_, float& a_, float& d_) { gmk_act_fwd(GMK_ACT_RELU, z_, a_, d_); }); break; \
+    case GMK_ACT_NONE: body([](float z_, float& a_, float& d_) { a_ = z_; d_ = 1.f; }); break;             \
+    default: { const int act__ = (act); body([act__](float z_, float& a_, float& d_) { gmk_act_fwd(act__, z_, a_, d_); }); } break; \
+  }
+
 // ---- buffer (SRD) loads: hardware bounds check returns 0 for out-of-range offsets, so padded /
 // masked tile loads need no branch and no select (an invalid lane passes GMK_OOB as its offset).
 #define GMK_OOB ((int)0x80000000)
