@@ -56,6 +56,7 @@ CONV_SHAPES = [
     (32, 16, 32, 32, 48, 3, 1),
     (512, 8, 8, 8, 16, 3, 1),
     (64, 24, 16, 16, 80, 3, 1),
+    (256, 8, 8, 16, 16, 3, 1),    # Winograd on non-square images (tile rows of 8, 4 tile rows per image)
     # channel counts that are not a multiple of the 8-channel K-chunk: pipelined full chunks + masked tail chunk,
     # odd / even numbers of full chunks (zero-weight padding chunk), stride 1 and 2 (dgrad runs the other modes)
     (2, 20, 16, 16, 12, 3, 1),
