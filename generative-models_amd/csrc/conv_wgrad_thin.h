@@ -9,7 +9,7 @@
 //
 // GEMM view: M = 64 wide channels (A operand), N = Ct*k*k (+1) columns padded to 32*NB (B operand, read
 // from the zero-padded thin patch in LDS at a per-lane tap offset), K = pixels.  The kernel is HBM-bound
-// (one pass over the wide tensor): 512-thread blocks each take 4 consecutive 256-pixel chunks, prefetch all of them into
+// (one pass over the wide tensor): 512-thread blocks each take GMK_THIN_CPB consecutive 256-pixel chunks, prefetch all of them into
 // registers and pass them through one LDS tile, each of the 8 waves reduces 32 pixels of the chunk, partials are combined in LDS in a fixed
 // order and one slab per block is written; a second kernel sums the slabs (deterministic, no atomics).
 #pragma once
@@ -31,7 +31,9 @@ struct ThinGeom {
 #define GMK_THIN_SS 260  /* LDS row stride of the wide tile (floats): 16-byte rows */
 #define GMK_THIN_THREADS 512
 #define GMK_THIN_TSLOT 3
-#define GMK_THIN_CPB 4  /* chunks per block */
+#ifndef GMK_THIN_CPB
+#define GMK_THIN_CPB 2  /* chunks per block (measured: 1 -> 35.5 us, 2 -> 29.6, 4 -> 31.6, 8 -> 58 per launch incl. reduce) */
+#endif
 
 template <int KS, int NB>
 __global__ __launch_bounds__(GMK_THIN_THREADS) void conv_wgrad_thin_kernel(const ThinGeom g) {
