@@ -196,7 +196,7 @@ def main():
     ap.add_argument("--no-fid", action="store_true", help="skip the FID-stats leg")
     args = ap.parse_args()
 
-    from gmk.parallel import init_from_env, GradReducer
+    from gmk.parallel import init_from_env, GradReducer, all_reduce_, broadcast_
     rank, local, world = init_from_env()
     if world != args.gpus:
         if rank == 0:
@@ -209,7 +209,7 @@ def main():
 
     model, optim, sched = build(device)
     if world > 1:  # identical replicas: broadcast rank 0's parameters
-        dist.broadcast(optim.flat_param, src=0)
+        broadcast_(optim.flat_param, src=0)
     reducer = GradReducer(model, optim)
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     batches = [torch.rand(PER_GPU_BATCH, 3, 32, 32, device=device, generator=gen) for _ in range(4)]
@@ -240,7 +240,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce_(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_losses = [float(v) for v in losses.cpu()]
 

@@ -12,6 +12,7 @@ N_PER_SET = 50000
 def fid_stats_leg(device, rank, world, n_per_set=N_PER_SET, reps=3):
     import metrics
     from gmk import ops
+    from gmk.parallel import all_reduce_, broadcast_
     from models.autoencoders import Autoencoder
     from utils import get_activation_function
     torch.manual_seed(0)
@@ -22,7 +23,7 @@ def fid_stats_leg(device, rank, world, n_per_set=N_PER_SET, reps=3):
         ae.encoder.fc.weight.mul_(40.0)   # sets do not collapse onto one point and the reported FID is not ~0
     if world > 1:
         for p in ae.parameters():
-            dist.broadcast(p.data, src=0)
+            broadcast_(p.data, src=0)
     local = n_per_set // world + (1 if rank < n_per_set % world else 0)
     gen = torch.Generator(device=device).manual_seed(99 + rank)
     real = torch.rand(local, 3, 32, 32, device=device, generator=gen)
@@ -44,7 +45,7 @@ def fid_stats_leg(device, rank, world, n_per_set=N_PER_SET, reps=3):
     dt = (time.perf_counter() - t0) / reps
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce_(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     # moments-only (features already resident) and the fixed sqrt-trace tail, rank-local

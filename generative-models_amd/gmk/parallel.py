@@ -11,6 +11,34 @@ import torch
 import torch.distributed as dist
 
 
+def _on_rccl(group=None):
+    return dist.is_initialized() and dist.get_backend(group) == "nccl"
+
+
+def all_reduce_(t, op=None, group=None):
+    """In-place all-reduce of a device tensor.  RCCL takes it as it is.  gloo (CPU tests, 1-GPU rehearsals) gets a host
+    copy: its device-tensor path hangs intermittently on this stack when two ranks share a card
+    (tools/rehearse/gloo_probe.py: plain torch, no libgmk)."""
+    op = dist.ReduceOp.SUM if op is None else op
+    if _on_rccl(group) or not t.is_cuda:
+        dist.all_reduce(t, op=op, group=group)
+    else:
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    return t
+
+
+def broadcast_(t, src=0, group=None):
+    if _on_rccl(group) or not t.is_cuda:
+        dist.broadcast(t, src=src, group=group)
+    else:
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    return t
+
+
 class GradReducer:
     def __init__(self, model, optimizer, process_group=None):
         self.group = process_group
@@ -23,6 +51,8 @@ class GradReducer:
         self.buckets = {"decoder": optimizer.segment(dec), "encoder.fc": optimizer.segment(enc_fc),
                         "encoder.conv": optimizer.segment(enc_conv)}
         self._work = []
+        # async device-tensor collectives only on RCCL; gloo (rehearsal / CPU-test transport) goes through all_reduce_()
+        self._async = _on_rccl(process_group)
         optimizer.grad_scale = 1.0 / self.world
 
     def ready(self, name):
@@ -30,7 +60,10 @@ class GradReducer:
         if self.world == 1:
             return
         a, b = self.buckets[name]
-        self._work.append(dist.all_reduce(self.opt.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self._async:
+            self._work.append(dist.all_reduce(self.opt.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            all_reduce_(self.opt.flat_grad[a:b], group=self.group)
 
     def wait(self):
         for w in self._work:
@@ -44,11 +77,18 @@ def init_from_env():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal knobs (a 1-GPU box cannot run RCCL between two ranks): GMK_DIST_BACKEND=gloo + GMK_FORCE_DEVICE=0 put
+    # every rank on one card and exchange device tensors over gloo; the code path above the transport is the same.
+    if os.environ.get("GMK_FORCE_DEVICE") is not None:
+        local = int(os.environ["GMK_FORCE_DEVICE"])
     if world > 1 and not dist.is_initialized():
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if torch.cuda.is_available():
+        backend = os.environ.get("GMK_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available() and backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        elif torch.cuda.is_available():
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():

@@ -49,7 +49,8 @@ def train_one_epoch(args, model, epoch=None, beta=None, train_dataloader=None, o
         count += 1
     if reducer is not None and reducer.world > 1:
         # every rank saw its own shard: report the mean over ranks (one 3-float all-reduce per epoch)
-        torch.distributed.all_reduce(total, group=reducer.group)
+        from gmk.parallel import all_reduce_
+        all_reduce_(total, group=reducer.group)
         total /= reducer.world
     avg_train_rec_loss = total[0] / len(train_dataloader)
     avg_train_kl_loss = beta * total[1] / len(train_dataloader) if args.variational else 0
@@ -155,7 +156,8 @@ def main(args):
         model.load_state_dict(checkpoint['state_dict'])
     if world > 1:
         for p in model.parameters():
-            torch.distributed.broadcast(p.data, src=0)
+            from gmk.parallel import broadcast_
+            broadcast_(p.data, src=0)
     optim = FusedAdamW(model.parameters(), lr=args.lr, weight_decay=args.wd)
     lr_scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optim, T_max=args.epochs * len(train_dataloader))
     reducer = GradReducer(model, optim) if world > 1 else None

@@ -19,6 +19,7 @@ import torch
 import torch.distributed as dist
 
 from gmk import ops
+from gmk.parallel import all_reduce_
 
 
 def _world(group=None):
@@ -54,7 +55,7 @@ def feature_moments(model, images, batch_size=1024, group=None, sharded=False):
             n += f.shape[0]
     packed[0] = n
     if sharded and _world(group) > 1:
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)  # the ONE exchange step of the FID path
+        all_reduce_(packed, group=group)  # the ONE exchange step of the FID path
     return int(round(packed[0].item())), s, G
 
 
@@ -89,7 +90,7 @@ def _logit_stats(classifier, images, N, eps, batch_size, group, sharded=False):
             logits = classifier(images[i:i + batch_size]).detach().float().contiguous()
             out = ops.softmax_stats(logits, out=out, topn=N, eps=eps)
     if sharded and _world(group) > 1:
-        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)  # the one exchange of the IS / conf / div path
+        all_reduce_(out, group=group)  # the one exchange of the IS / conf / div path
     C = (out.numel() - 4) // 2
     return out, C
 

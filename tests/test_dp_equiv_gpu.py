@@ -212,3 +212,24 @@ def test_two_rank_dp_step_and_metrics_over_gloo_on_one_gpu():
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
 def test_two_rank_dp_step_and_metrics_over_rccl():
     _run_two_ranks("nccl", 2)
+
+
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """bench.py's multi-rank flow end to end (rendezvous from the torchrun environment, replica broadcast, GradReducer
+    buckets from train_step, barrier + max-over-ranks timing, sharded FID leg, rank-0 JSON line) with two ranks on ONE card:
+    GMK_DIST_BACKEND=gloo + GMK_FORCE_DEVICE=0.  Only the transport differs from the driver's N-GPU run (gloo through
+    host copies instead of RCCL)."""
+    import json
+    import subprocess
+    env = dict(os.environ, GMK_DIST_BACKEND="gloo", GMK_FORCE_DEVICE="0", PYTHONUNBUFFERED="1")
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 512 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and np.isfinite(out["final_losses"]["total"])
+    assert out["fid_stats"]["samples"] == 100000 and np.isfinite(out["fid_stats"]["fid"])
