@@ -218,7 +218,8 @@ def main():
 
     def step(i):
         eps = torch.randn(PER_GPU_BATCH, 256, device=device, generator=egen)
-        losses = model.train_step(batches[i % len(batches)], beta=beta, eps=eps, reducer=reducer)
+        losses = model.train_step(batches[i % len(batches)], beta=beta, eps=eps, reducer=reducer,
+                                  optimizer=None if os.environ.get("GMK_EARLY_ADAMW", "0") == "0" else optim)
         reducer.wait()
         optim.step()
         sched.step()

@@ -74,9 +74,11 @@ def encoder_backward(p, sv, dout, *, no_pool, ksize, gout=None, on_fc_done=None,
     x = sv["x"]
     a5 = sv["a5"]
     g["fc.weight"], g["fc.bias"] = _wg(side, lambda: ops.linear_wgrad(dout, a5.view(B, -1), out=_o(gout, "fc")), dout)
-    if on_fc_done is not None:
-        on_fc_done()  # fc gradients are enqueued: their all-reduce can start under the conv backward
     dz5 = ops.linear_dgrad(dout, p["fc.weight"], dact_in=sv["d5"].view(B, -1)).view_as(a5)
+    if on_fc_done is not None:
+        # fc gradients are enqueued and the last reader of fc.weight (the dgrad above) is too: the bucket's all-reduce
+        # -- and its early AdamW update -- can start under the conv backward
+        on_fc_done()
     g["conv3.weight"], g["conv3.bias"] = _wg(side, lambda: ops.conv2d_wgrad(dz5, sv["a4"], ksize, 1, out=_o(gout, "conv3")), dz5)
     if no_pool:
         dz4 = ops.conv2d_dgrad(dz5, p["conv3.weight"], tuple(sv["a4"].shape), 1, dact_in=sv["d4"])

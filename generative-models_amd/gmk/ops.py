@@ -11,8 +11,31 @@ from ._lib import lib, check, act_id, UPSAMPLE_IDS
 _ws_cache = {}
 
 
+# Stream handle override: torch.cuda.current_stream() costs ~7 us of host time per call and every op asks for it; at ~80
+# launches per train step that alone was half of the 1.0 ms of host time that bounds the B = 256 step.  train_step sets
+# the handle once (stream_scope) and the side queue swaps it around the calls it redirects.
+_cur_stream = None
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _cur_stream if _cur_stream is not None else torch.cuda.current_stream().cuda_stream
+
+
+class stream_scope:
+    """with stream_scope(torch_stream): every gmk op inside launches on `torch_stream` (which must be torch's current
+    stream, so that torch's allocator and ops agree) without asking torch for it again."""
+
+    def __init__(self, stream):
+        self.handle = stream.cuda_stream
+
+    def __enter__(self):
+        global _cur_stream
+        self.prev = _cur_stream
+        _cur_stream = self.handle
+
+    def __exit__(self, *exc):
+        global _cur_stream
+        _cur_stream = self.prev
 
 
 def _p(t):
@@ -30,8 +53,7 @@ def _chk(*ts):
 def workspace(nbytes, device):
     """A cached byte workspace per (device, current stream), grown on demand: kernels of one stream run in
     order, so they can share scratch; two streams (the wgrad side queue) must not."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -56,17 +78,31 @@ class SideQueue:
         self.stream = self.streams[0]
         self._next = 0
         self._keep = []
+        self._main = None
+        self._handles = [st.cuda_stream for st in self.streams]
+
+    def begin(self, main_stream):
+        """Names the stream that run() forks from until join() (saves a torch.cuda.current_stream() per call)."""
+        self._main = main_stream
 
     def run(self, fn, *tensors):
-        """fn() is enqueued on a side stream after everything enqueued so far on the current stream."""
+        """fn() is enqueued on a side stream after everything enqueued so far on the main stream.  The gmk ops inside
+        launch on the side stream through the handle override; torch's own current stream is left alone (fn must not
+        allocate tensors that die before join(): the weight-gradient calls write into the flat gradient buffer)."""
+        global _cur_stream
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
-        st = self.streams[self._next]
-        self._next = (self._next + 1) % len(self.streams)
+        ev.record(self._main if self._main is not None else torch.cuda.current_stream(self.device))
+        i = self._next
+        st = self.streams[i]
+        self._next = (i + 1) % len(self.streams)
         st.wait_event(ev)
         self._keep.extend(tensors)
-        with torch.cuda.stream(st):
+        prev = _cur_stream
+        _cur_stream = self._handles[i]
+        try:
             return fn()
+        finally:
+            _cur_stream = prev
 
     def gather(self):
         """Orders streams[0] behind the other side streams (so that work enqueued on it next, e.g. a gradient bucket's
@@ -76,14 +112,39 @@ class SideQueue:
 
     def join(self):
         """The current stream waits for all side work; kept tensors may be freed afterwards."""
-        cur = torch.cuda.current_stream(self.device)
+        cur = self._main if self._main is not None else torch.cuda.current_stream(self.device)
         for st in self.streams:
             cur.wait_stream(st)
         self._next = 0
+        self._main = None
         self._keep.clear()
 
 
 _side_cache = {}
+_aux_cache = {}
+_seg_cache = {}
+
+
+def aux_stream(device):
+    """A third stream per device (early AdamW updates of finished gradient buckets)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _aux_cache.get(key)
+    if st is None:
+        st = _aux_cache[key] = torch.cuda.Stream(torch.device("cuda", key))
+    return st
+
+
+def bucket_segments(model, optimizer):
+    """Flat (start, end) ranges of the three gradient buckets of an Autoencoder in `optimizer`'s buffers (the same split
+    as gmk.parallel.GradReducer), cached per (model, optimizer)."""
+    key = (id(model), id(optimizer), optimizer.flat_param.data_ptr())
+    seg = _seg_cache.get(key)
+    if seg is None:
+        enc_fc = [model.encoder.fc.weight, model.encoder.fc.bias]
+        enc_conv = [p for n, p in model.encoder.named_parameters() if not n.startswith("fc.")]
+        seg = _seg_cache[key] = {"decoder": optimizer.segment(list(model.decoder.parameters())),
+                                 "encoder.fc": optimizer.segment(enc_fc), "encoder.conv": optimizer.segment(enc_conv)}
+    return seg
 
 
 def side_queue(device):

@@ -8,6 +8,7 @@ gradient buffer is also what the data-parallel reducer all-reduces (gmk/parallel
 """
 import torch
 
+from .ops import _stream as ops_stream
 from ._lib import lib, check
 
 
@@ -28,6 +29,7 @@ class FusedAdamW(torch.optim.AdamW):
         if len(self.param_groups) != 1:
             raise NotImplementedError("FusedAdamW supports a single param group (the reference uses one)")
         self.grad_scale = 1.0  # set to 1/world_size by the DP reducer (SUM all-reduce)
+        self._early = []       # flat ranges already updated by step_range() for the step in progress
         self._flatten()
 
     # ------------------------------------------------------------------ flat storage
@@ -91,9 +93,7 @@ class FusedAdamW(torch.optim.AdamW):
         super().load_state_dict(state_dict)
         self._flatten()
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        loss = closure() if closure is not None else None
+    def _prepare(self):
         if not self._views_ok():
             self._flatten()  # someone re-assigned p.data / p.grad (e.g. model.to()): re-home them
         group = self.param_groups[0]
@@ -108,11 +108,37 @@ class FusedAdamW(torch.optim.AdamW):
                 n = p.numel()
                 st["exp_avg"] = self.flat_m[o:o + n].view(p.shape)
                 st["exp_avg_sq"] = self.flat_v[o:o + n].view(p.shape)
-            st["step"] += 1
-        step = int(self.state[ps[0]]["step"].item())
+        return group, ps
+
+    def _launch(self, group, a, b, step):
         b1, b2 = group["betas"]
-        check(lib().gmk_adamw_step(self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.flat_m.data_ptr(),
-                                   self.flat_v.data_ptr(), self._numel, float(group["lr"]), float(b1), float(b2),
-                                   float(group["eps"]), float(group["weight_decay"]), step, float(self.grad_scale),
-                                   torch.cuda.current_stream().cuda_stream))
+        check(lib().gmk_adamw_step(self.flat_param.data_ptr() + 4 * a, self.flat_grad.data_ptr() + 4 * a,
+                                   self.flat_m.data_ptr() + 4 * a, self.flat_v.data_ptr() + 4 * a, b - a, float(group["lr"]),
+                                   float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), step,
+                                   float(self.grad_scale), ops_stream()))
+
+    @torch.no_grad()
+    def step_range(self, a, b):
+        """AdamW on the flat range [a, b) NOW, on the current stream, as an early part of the step that the next step()
+        call completes: step() then updates only the ranges not yet done and advances the step count once.  Lets
+        Autoencoder.train_step(optimizer=...) update a gradient bucket as soon as it is final, under the rest of backward
+        (same arithmetic, same step number, same lr as the step() that follows)."""
+        group, ps = self._prepare()
+        step = int(self.state[ps[0]]["step"].item()) + 1
+        self._launch(group, a, b, step)
+        self._early.append((a, b))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        group, ps = self._prepare()
+        for p in ps:
+            self.state[p]["step"] += 1
+        step = int(self.state[ps[0]]["step"].item())
+        pos = 0
+        for a, b in sorted(self._early) + [(self._numel, self._numel)]:   # the complement of the early ranges
+            if a > pos:
+                self._launch(group, pos, a, step)
+            pos = max(pos, b)
+        self._early = []
         return loss

@@ -51,6 +51,7 @@ class GradReducer:
         self.buckets = {"decoder": optimizer.segment(dec), "encoder.fc": optimizer.segment(enc_fc),
                         "encoder.conv": optimizer.segment(enc_conv)}
         self._work = []
+        self._by_name = {}
         # async device-tensor collectives only on RCCL; gloo (rehearsal / CPU-test transport) goes through all_reduce_()
         self._async = _on_rccl(process_group)
         optimizer.grad_scale = 1.0 / self.world
@@ -61,14 +62,23 @@ class GradReducer:
             return
         a, b = self.buckets[name]
         if self._async:
-            self._work.append(dist.all_reduce(self.opt.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            w = dist.all_reduce(self.opt.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._work.append(w)
+            self._by_name[name] = w
         else:
             all_reduce_(self.opt.flat_grad[a:b], group=self.group)
+
+    def wait_bucket(self, name):
+        """Orders the CURRENT stream behind bucket `name`'s all-reduce (no host wait on RCCL; gloo reduced synchronously)."""
+        w = self._by_name.pop(name, None)
+        if w is not None:
+            w.wait()
 
     def wait(self):
         for w in self._work:
             w.wait()
         self._work = []
+        self._by_name = {}
 
 
 def init_from_env():

@@ -284,7 +284,7 @@ class Autoencoder(nn.Module):
         return out5
 
     # ------------------------------------------------------------------ fused train step
-    def train_step(self, image, beta=0.0, mse_prior=False, eps=None, reducer=None):
+    def train_step(self, image, beta=0.0, mse_prior=False, eps=None, reducer=None, optimizer=None):
         """Forward + fused loss + backward of /root/reference/main.py:29-51 without autograd.
 
         Overwrites `.grad` of every parameter (what zero_grad + backward leave behind) and returns a
@@ -292,59 +292,87 @@ class Autoencoder(nn.Module):
         stays with the caller (main.py:52-53).  `eps` replaces torch.randn for parity tests.
         `reducer` (gmk.parallel.GradReducer) is told as soon as each gradient bucket is enqueued so
         that its all-reduce overlaps the rest of backward.
+        `optimizer` (gmk.optim.FusedAdamW, optional): the decoder and encoder.fc buckets (95 % of the parameters) get
+        their AdamW update as soon as their gradients are final (and all-reduced), on a third stream under the encoder's
+        backward pass -- nothing later in backward reads those weights.  The caller still calls optimizer.step() after
+        train_step, as main.py:52 does: it updates the rest and advances the step count (FusedAdamW.step_range).
+        Bit-identical to the plain order; measured at B = 256 on one GPU it hides 15 us of GPU time and costs 120 us of
+        host time in a step whose host time (0.85 ms) is close to its GPU time (1.05 ms), so nothing passes it by default.
         """
-        sigmoid = bool(self.decoder.use_sigmoid)
-        enc, dec = self.encoder, self.decoder
-        pe = {n: p.data for n, p in enc.named_parameters()}
-        pd = {n: p.data for n, p in dec.named_parameters()}
-        for p in self.parameters():
-            if p.grad is None:
-                p.grad = torch.empty_like(p.data)
-        ge = {n: p.grad for n, p in enc.named_parameters()}
-        gd = {n: p.grad for n, p in dec.named_parameters()}
-        image = image.contiguous()
-        B = image.shape[0]
-        if self.variational:
-            if eps is None:
-                eps = torch.randn((B, self.latent_size), device=image.device, dtype=torch.float32)
-            eps = eps.contiguous()
-            # encoder head + reparameterisation: one GEMM whose reduction epilogue writes stats and z
-            stats, sve = engine.encoder_forward(pe, image, act=enc._act_id, no_pool=enc.no_pool, ksize=enc.kernel_size,
-                                                train=True, reparam_eps=eps)
-            z = sve["z"]
-            self.stats, self.normal = stats, eps
-        else:
-            out, sve = engine.encoder_forward(pe, image, act=enc._act_id, no_pool=enc.no_pool, ksize=enc.kernel_size, train=True)
-            stats, z = None, out
-        self.latent_vector = z
-        pre, svd = engine.decoder_forward(pd, z, act=dec._act_id, num_channels=dec.num_channels,
-                                          no_upsample=dec.no_upsample, interpolation=dec._interp,
-                                          ksize=dec.kernel_size, base=dec.base, train=True, final_act=None)
-        # sigmoid + MSE + beta*KL and d/d pre in one pass; the KL gradient rides with the reparameterisation backward in
-        # the decoder fc's dgrad epilogue below, so no dstats round trip and no separate reparam launches
-        losses, dpre, _, _ = ops.vae_loss_fwd_bwd(pre, image, stats, beta, sigmoid=sigmoid, mse_prior=mse_prior,
-                                                  want_dstats=False, fused=True)
-        # weight gradients run on a side stream, overlapping the dgrad chain on this one (gmk.ops.SideQueue)
-        side = ops.side_queue(image.device)
+        # one stream lookup per step: every gmk op below takes the handle from the scope (gmk.ops.stream_scope)
+        main_stream = torch.cuda.current_stream(image.device)
+        with ops.stream_scope(main_stream):
+            sigmoid = bool(self.decoder.use_sigmoid)
+            enc, dec = self.encoder, self.decoder
+            pe = {n: p.data for n, p in enc.named_parameters()}
+            pd = {n: p.data for n, p in dec.named_parameters()}
+            for p in self.parameters():
+                if p.grad is None:
+                    p.grad = torch.empty_like(p.data)
+            ge = {n: p.grad for n, p in enc.named_parameters()}
+            gd = {n: p.grad for n, p in dec.named_parameters()}
+            image = image.contiguous()
+            B = image.shape[0]
+            if self.variational:
+                if eps is None:
+                    eps = torch.randn((B, self.latent_size), device=image.device, dtype=torch.float32)
+                eps = eps.contiguous()
+                # encoder head + reparameterisation: one GEMM whose reduction epilogue writes stats and z
+                stats, sve = engine.encoder_forward(pe, image, act=enc._act_id, no_pool=enc.no_pool, ksize=enc.kernel_size,
+                                                    train=True, reparam_eps=eps)
+                z = sve["z"]
+                self.stats, self.normal = stats, eps
+            else:
+                out, sve = engine.encoder_forward(pe, image, act=enc._act_id, no_pool=enc.no_pool, ksize=enc.kernel_size, train=True)
+                stats, z = None, out
+            self.latent_vector = z
+            pre, svd = engine.decoder_forward(pd, z, act=dec._act_id, num_channels=dec.num_channels,
+                                              no_upsample=dec.no_upsample, interpolation=dec._interp,
+                                              ksize=dec.kernel_size, base=dec.base, train=True, final_act=None)
+            # sigmoid + MSE + beta*KL and d/d pre in one pass; the KL gradient rides with the reparameterisation backward in
+            # the decoder fc's dgrad epilogue below, so no dstats round trip and no separate reparam launches
+            losses, dpre, _, _ = ops.vae_loss_fwd_bwd(pre, image, stats, beta, sigmoid=sigmoid, mse_prior=mse_prior,
+                                                      want_dstats=False, fused=True)
+            # weight gradients run on a side stream, overlapping the dgrad chain on this one (gmk.ops.SideQueue)
+            side = ops.side_queue(image.device)
+            if side is not None:
+                side.begin(main_stream)
 
-        def bucket_ready(name):
-            if reducer is None:
-                return
-            if side is None:
-                reducer.ready(name)
-            else:  # the bucket's gradients are ordered on the side stream(s): the all-reduce waits for them
-                side.gather()
-                with torch.cuda.stream(side.stream):
-                    reducer.ready(name)
+            early = optimizer is not None and side is not None and hasattr(optimizer, "step_range")
+            if early:
+                seg = ops.bucket_segments(self, optimizer)
+                opt_stream = ops.aux_stream(image.device)
 
-        rp = (stats, eps, float(beta) / B, mse_prior) if self.variational else None
-        _, dz = engine.decoder_backward(pd, svd, dpre, no_upsample=dec.no_upsample, interpolation=dec._interp,
-                                        ksize=dec.kernel_size, need_dz=True, gout=gd, side=side, reparam=rp)
-        bucket_ready("decoder")
-        dout = dz.view(B, -1)
-        engine.encoder_backward(pe, sve, dout, no_pool=enc.no_pool, ksize=enc.kernel_size, gout=ge,
-                                on_fc_done=lambda: bucket_ready("encoder.fc"), side=side)
-        bucket_ready("encoder.conv")
-        if side is not None:
-            side.join()
+            def bucket_ready(name):
+                if reducer is not None:
+                    if side is None:
+                        reducer.ready(name)
+                    else:  # the bucket's gradients are ordered on the side stream(s): the all-reduce waits for them
+                        side.gather()
+                        with torch.cuda.stream(side.stream):
+                            reducer.ready(name)
+                if early and name != "encoder.conv":
+                    # the update must follow the bucket's weight gradients (side stream), the kernels that read its weights
+                    # (main stream, all enqueued by now) and its all-reduce
+                    side.gather()
+                    opt_stream.wait_stream(side.stream)
+                    opt_stream.wait_stream(main_stream)
+                    if reducer is not None:   # RCCL work handles order torch's current stream
+                        with torch.cuda.stream(opt_stream):
+                            reducer.wait_bucket(name)
+                    with ops.stream_scope(opt_stream):
+                        optimizer.step_range(*seg[name])
+
+            rp = (stats, eps, float(beta) / B, mse_prior) if self.variational else None
+            _, dz = engine.decoder_backward(pd, svd, dpre, no_upsample=dec.no_upsample, interpolation=dec._interp,
+                                            ksize=dec.kernel_size, need_dz=True, gout=gd, side=side, reparam=rp)
+            bucket_ready("decoder")
+            dout = dz.view(B, -1)
+            engine.encoder_backward(pe, sve, dout, no_pool=enc.no_pool, ksize=enc.kernel_size, gout=ge,
+                                    on_fc_done=lambda: bucket_ready("encoder.fc"), side=side)
+            bucket_ready("encoder.conv")
+            if side is not None:
+                side.join()
+        if early:
+            main_stream.wait_stream(opt_stream)
         return losses

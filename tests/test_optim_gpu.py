@@ -183,3 +183,34 @@ def test_resume_from_reference_written_checkpoint(extra_golden):
     for (p, q) in zip(m.parameters(), stock.param_groups[0]["params"]):
         assert torch.equal(stock.state[q]["exp_avg"], opt.state[p]["exp_avg"].cpu())
         assert float(stock.state[q]["step"]) == 3.0
+
+
+def test_early_bucket_updates_equal_one_step():
+    """train_step(optimizer=...) updates the decoder and encoder.fc buckets under the encoder's backward and step() the rest:
+    parameters, moments and step counts after 5 steps are bit-identical to train_step() + one full step()."""
+    from models.autoencoders import Autoencoder
+    from utils import get_activation_function
+    from gmk.optim import FusedAdamW
+    dev = torch.device("cuda:0")
+
+    def run(early):
+        torch.manual_seed(0)
+        m = Autoencoder(variational=True, latent_size=256, num_channels=64, kernel_size=3, act=get_activation_function("gelu"),
+                        sigmoid=True, interpolation="nearest", no_pool=True, no_upsample=True, device=dev).to(dev)
+        opt = FusedAdamW(m.parameters(), lr=1e-3, weight_decay=0.01)
+        sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=20)
+        g = torch.Generator(device=dev).manual_seed(3)
+        for _ in range(5):
+            x = torch.rand(64, 3, 32, 32, device=dev, generator=g)
+            eps = torch.randn(64, 256, device=dev, generator=g)
+            m.train_step(x, beta=1e-3, eps=eps, optimizer=opt if early else None)
+            opt.step()
+            sched.step()
+        torch.cuda.synchronize()
+        steps = {float(opt.state[p]["step"]) for p in opt.param_groups[0]["params"]}
+        return opt.flat_param.clone(), opt.flat_m.clone(), opt.flat_v.clone(), steps
+
+    pa, ma, va, sa = run(False)
+    pb, mb, vb, sb = run(True)
+    assert sa == sb == {5.0}
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)

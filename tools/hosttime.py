@@ -9,7 +9,7 @@ model, optim, sched = bench.build(dev)
 x = torch.rand(256, 3, 32, 32, device=dev)
 eps = torch.randn(256, 256, device=dev)
 def step():
-    l = model.train_step(x, beta=5e-6, eps=eps)
+    l = model.train_step(x, beta=5e-6, eps=eps, optimizer=optim if os.environ.get("GMK_EARLY_ADAMW", "0") != "0" else None)
     optim.step(); sched.step()
 for _ in range(20): step()
 torch.cuda.synchronize()

@@ -16,13 +16,14 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 device = torch.device("cuda:0")
 model, optim, sched = bench.build(device)
 gen = torch.Generator(device=device).manual_seed(1234)
-batches = [torch.rand(256, 3, 32, 32, device=device, generator=gen) for _ in range(4)]
+B = int(os.environ.get("KB_BATCH", "256"))
+batches = [torch.rand(B, 3, 32, 32, device=device, generator=gen) for _ in range(4)]
 egen = torch.Generator(device=device).manual_seed(4321)
 
 
 def step(i):
-    eps = torch.randn(256, 256, device=device, generator=egen)
-    model.train_step(batches[i % 4], beta=5e-6, eps=eps)
+    eps = torch.randn(B, 256, device=device, generator=egen)
+    model.train_step(batches[i % 4], beta=5e-6, eps=eps, optimizer=None if os.environ.get("GMK_EARLY_ADAMW", "0") == "0" else optim)
     optim.step()
     sched.step()
 
