@@ -19,6 +19,7 @@ _F = C.c_float
 # name -> (restype, argtypes); mirrors include/gmk.h one to one
 SIGNATURES = {
     "gmk_version": (_I, []),
+    "gmk_stream_wait_stream": (_I, [_P, _P]),
     "gmk_strerror": (C.c_char_p, [_I]),
     "gmk_conv2d_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "gmk_conv2d_dgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -90,12 +90,10 @@ class SideQueue:
         launch on the side stream through the handle override; torch's own current stream is left alone (fn must not
         allocate tensors that die before join(): the weight-gradient calls write into the flat gradient buffer)."""
         global _cur_stream
-        ev = torch.cuda.Event()
-        ev.record(self._main if self._main is not None else torch.cuda.current_stream(self.device))
+        main = self._main if self._main is not None else torch.cuda.current_stream(self.device)
         i = self._next
-        st = self.streams[i]
         self._next = (i + 1) % len(self.streams)
-        st.wait_event(ev)
+        check(lib().gmk_stream_wait_stream(self._handles[i], main.cuda_stream))
         self._keep.extend(tensors)
         prev = _cur_stream
         _cur_stream = self._handles[i]
@@ -113,8 +111,8 @@ class SideQueue:
     def join(self):
         """The current stream waits for all side work; kept tensors may be freed afterwards."""
         cur = self._main if self._main is not None else torch.cuda.current_stream(self.device)
-        for st in self.streams:
-            cur.wait_stream(st)
+        for h in self._handles:
+            check(lib().gmk_stream_wait_stream(cur.cuda_stream, h))
         self._next = 0
         self._main = None
         self._keep.clear()

@@ -51,6 +51,11 @@ enum gmk_act {
 };
 
 int gmk_version(void);
+/* gmk_stream_wait_stream: everything enqueued on `waiter` after this call runs behind everything enqueued on `on`
+ *   before it (hipEventRecord + hipStreamWaitEvent on an event of a per-device ring of 64, created on first use).
+ *   No counterpart in the reference: host plumbing of the backward pass's second stream (weight gradients), which
+ *   autograd's single stream does not have (main.py:51). */
+int gmk_stream_wait_stream(gmk_stream_t waiter, gmk_stream_t on);
 const char* gmk_strerror(int code);
 
 /* ---------------------------------------------------------------- convolutions ----------
