@@ -69,9 +69,9 @@ class SideQueue:
 
     def __init__(self, device):
         self.device = device
-        # stream priority knob (GMK_SIDE_PRIORITY=-1 = high): measured 2 % slower than equal priorities on one device,
-        # so the default stays 0
-        prio = int(os.environ.get("GMK_SIDE_PRIORITY", "0"))
+        # stream priority (GMK_SIDE_PRIORITY, -1 = high, the default): the weight-gradient streams are the longer path of
+        # backward; 1.025 -> 1.017 ms per step with two side streams (round 1, host-bound: 2 % slower)
+        prio = int(os.environ.get("GMK_SIDE_PRIORITY", "-1"))
         # GMK_SIDE_STREAMS=n: the weight-gradient launches alternate over n side streams.  Default 2: 1.056 -> 1.021 ms per step
         # once the host stopped bounding the step (1 -> 2 -> 3 -> 4 streams: 1.056 / 1.021 / 1.021 / 1.040 ms; while the step was
         # host-bound, round 2 first measured two streams 1-3 % slower)
