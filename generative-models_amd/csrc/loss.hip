@@ -3,6 +3,7 @@
 // write dpre, read stats, write dstats.  One pass, float4 per lane, wave64 shuffle reduction,
 // per-block fp64 partials, fixed-order 1-block finalize (deterministic).
 #include "gmk_common.h"
+#include <stdlib.h>
 #include <mutex>
 
 #define LOSS_BLOCKS 1024
@@ -160,7 +161,10 @@ static int vae_loss_launch(const float* pre, const float* image, const float* st
   if (recon_out) GMK_REQUIRE(gmk_aligned16(recon_out), GMK_E_ALIGN);
   hipStream_t s = (hipStream_t)stream;
   const int64_t n4 = B * chw / 4, nstat = variational ? B * L : 0;
-  int64_t want = (n4 + LOSS_THREADS - 1) / LOSS_THREADS;
+  // float4 items per thread: small launches (B = 256: 196,608 items) are a chain of round trips -- load, block sum,
+  // partial store + ticket, the last block's read of every partial -- and fewer, fatter blocks shorten the last one
+  static const int per_thread = getenv("GMK_LOSS_PER_THREAD") ? atoi(getenv("GMK_LOSS_PER_THREAD")) : 4;  // 1 -> 4: -4 us of step
+  int64_t want = (n4 + (int64_t)LOSS_THREADS * per_thread - 1) / ((int64_t)LOSS_THREADS * per_thread);
   int nblocks = (int)(want < LOSS_BLOCKS ? (want < 1 ? 1 : want) : LOSS_BLOCKS);
   const float gscale = (float)(2.0 / ((double)B * (double)chw));
   const float kscale = (float)((double)beta / (double)B);

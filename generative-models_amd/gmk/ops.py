@@ -69,9 +69,11 @@ class SideQueue:
 
     def __init__(self, device):
         self.device = device
-        # stream priority (GMK_SIDE_PRIORITY, -1 = high, the default): the weight-gradient streams are the longer path of
-        # backward; 1.025 -> 1.017 ms per step with two side streams (round 1, host-bound: 2 % slower)
-        prio = int(os.environ.get("GMK_SIDE_PRIORITY", "-1"))
+        # stream priority knob (GMK_SIDE_PRIORITY=-1 = high).  High-priority weight-gradient streams are 0.8 % faster in a
+        # single process (1.025 -> 1.017 ms) but HANG when two processes share a card (the 2-rank rehearsal test, 3 of 3
+        # runs; priority 0: never): a high-priority queue waiting on an event of a queue that is not scheduled.  A DP
+        # job also runs more queues than the 4 hardware queues of a process (RCCL's), so the default stays 0.
+        prio = int(os.environ.get("GMK_SIDE_PRIORITY", "0"))
         # GMK_SIDE_STREAMS=n: the weight-gradient launches alternate over n side streams.  Default 2: 1.056 -> 1.021 ms per step
         # once the host stopped bounding the step (1 -> 2 -> 3 -> 4 streams: 1.056 / 1.021 / 1.021 / 1.040 ms; while the step was
         # host-bound, round 2 first measured two streams 1-3 % slower)

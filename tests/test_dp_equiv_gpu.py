@@ -138,11 +138,12 @@ def _dp_worker(rank, world, port, backend, ngpu, q):
         # replicas stay identical: every rank holds the same parameters after the step
         flat = opt.flat_param.clone()
         ref_flat = flat.clone()
-        dist.broadcast(ref_flat, src=0)
+        from gmk.parallel import all_reduce_, broadcast_   # gloo: host copies (its device-tensor path can hang, see parallel.py)
+        broadcast_(ref_flat, src=0)
         assert torch.equal(flat, ref_flat)
         # mean of the per-rank losses == global-batch loss
         tot = losses.double().clone()
-        dist.all_reduce(tot)
+        all_reduce_(tot)
         assert abs(float(tot[2]) / world - float(o["total"])) <= 1e-4 * float(o["total"])
         # FID path: each rank passes ITS shard, one all-reduce of (n, s, G) (metrics.feature_moments, sharded=True)
         f1 = _fid_features("fid/set1", 3000, 256, 0.5, 1.0)
