@@ -10,6 +10,10 @@ bool gmk_thin_out_ok(int N, int Cin, int H, int W, int Cout, int ksize, int stri
 int gmk_launch_conv_thin_out(const float* x, const float* w, const float* bias, float* y, float* dact, int N, int Cin,
                              int H, int W, int Cout, int ksize, int act, hipStream_t s);
 
+// conv_thin_in.hip: stride-1 3x3 convs with <= 4 input channels (enc.conv1 forward, dec.conv3 data gradient)
+bool gmk_thin_in_ok(const ConvGeom& g, int ksize, int mode);
+int gmk_launch_conv_thin_in(const ConvGeom& g, hipStream_t s);
+
 static int conv_common_checks(int N, int Cin, int H, int W, int Cout, int ksize) {
   if (N <= 0 || Cin <= 0 || Cout <= 0) return GMK_E_SHAPE;
   if (!gmk_is_pow2(H) || !gmk_is_pow2(W) || H < 4 || W < 4 || W > 128) return GMK_E_SHAPE;
@@ -20,6 +24,10 @@ static int conv_common_checks(int N, int Cin, int H, int W, int Cout, int ksize)
 static int dispatch(ConvGeom& g, int ksize, int mode, hipStream_t s) {
   static const int dbg = getenv("GMK_CONV_DBG") ? atoi(getenv("GMK_CONV_DBG")) : 0;  // profiling ablations only
   g.dbg = dbg;
+  // <= 4 input channels (the image side of the autoencoder): output-stream bound, no GEMM (conv_thin_in.hip); GMK_THIN_IN=0
+  // keeps the implicit GEMM (A/B runs)
+  static const int thin_in = getenv("GMK_THIN_IN") ? atoi(getenv("GMK_THIN_IN")) : 3;   // bit 0: forward, bit 1: data gradient
+  if ((thin_in & (g.epi == 0 ? 1 : 2)) && !dbg && gmk_thin_in_ok(g, ksize, mode)) return gmk_launch_conv_thin_in(g, s);
   // stride-1 3x3 layers whose grid fills the chip (>= GMK_WINO_MIN_BLOCKS blocks of 32 tiles x 64 channels): Winograd
   // F(2x2,3x3) (conv_wino.h).  GMK_WINO: bit 0 = forward, bit 1 = data gradient; 0 keeps the implicit GEMM everywhere
   static const int wino_mask = getenv("GMK_WINO") ? atoi(getenv("GMK_WINO")) : 3;

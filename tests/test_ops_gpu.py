@@ -57,6 +57,14 @@ CONV_SHAPES = [
     (512, 8, 8, 8, 16, 3, 1),
     (64, 24, 16, 16, 80, 3, 1),
     (256, 8, 8, 16, 16, 3, 1),    # Winograd on non-square images (tile rows of 8, 4 tile rows per image)
+    # <= 4 channels on the image side and >= 1024 pixels: forward (thin input) and data gradient (thin output of the
+    # conv) run conv_thin_in.hip: odd channel count across two channel blocks, 2 and 4 channels, wide and narrow rows
+    (2, 3, 32, 32, 21, 3, 1),
+    (1, 2, 16, 64, 10, 3, 1),
+    (2, 4, 128, 8, 10, 3, 1),
+    (2, 21, 32, 32, 3, 3, 1),
+    (1, 10, 64, 64, 4, 3, 1),
+    (2, 10, 128, 8, 2, 3, 1),
     # channel counts that are not a multiple of the 8-channel K-chunk: pipelined full chunks + masked tail chunk,
     # odd / even numbers of full chunks (zero-weight padding chunk), stride 1 and 2 (dgrad runs the other modes)
     (2, 20, 16, 16, 12, 3, 1),
