@@ -64,6 +64,9 @@ const char* gmk_strerror(int code);
  * Stride-1 3x3 layers with Cin % 8 == 0, Cout % 16 == 0, width <= 32 and at least 256 blocks of 128 output pixels x 64
  * channels run as Winograd F(2x2,3x3) in fp32 (forward and data gradient; same operands, same results up to fp32
  * rounding, ~3e-7 of the output scale); GMK_WINO=0 in the environment keeps the implicit GEMM everywhere.
+ * Stride-1 3x3 layers with <= 4 channels on the image side and H*W >= 1024 (forward of a Cin <= 4 layer, data gradient
+ * of a Cout <= 4 layer) run on the vector ALUs as packed fp32 FMAs (conv_thin_in.hip: bound by the output stream);
+ * GMK_THIN_IN=0 keeps the implicit GEMM.
  *
  * gmk_conv2d_fwd: y = act(conv2d(x, w) + bias); if dact != NULL also writes act'(pre-activation)
  *   (the backward pass multiplies by it instead of re-evaluating erf/exp).
