@@ -14,6 +14,11 @@ int gmk_launch_conv_thin_out(const float* x, const float* w, const float* bias, 
 bool gmk_thin_in_ok(const ConvGeom& g, int ksize, int mode);
 int gmk_launch_conv_thin_in(const ConvGeom& g, hipStream_t s);
 
+// conv_thin_outv.hip: forward of stride-1 3x3 convs with <= 4 output channels on the vector ALUs (dec.conv3)
+bool gmk_thin_outv_ok(int N, int Cin, int H, int W, int Cout, int ksize, int stride);
+int gmk_launch_conv_thin_outv(const float* x, const float* w, const float* bias, float* y, float* dact, int N, int Cin,
+                              int H, int W, int Cout, int act, hipStream_t s);
+
 static int conv_common_checks(int N, int Cin, int H, int W, int Cout, int ksize) {
   if (N <= 0 || Cin <= 0 || Cout <= 0) return GMK_E_SHAPE;
   if (!gmk_is_pow2(H) || !gmk_is_pow2(W) || H < 4 || W < 4 || W > 128) return GMK_E_SHAPE;
@@ -49,6 +54,9 @@ extern "C" int gmk_conv2d_fwd(const float* x, const float* w, const float* bias,
   if (rc) return rc;
   GMK_REQUIRE(stride == 1 || stride == 2, GMK_E_UNSUPPORTED);
   GMK_REQUIRE(act >= GMK_ACT_NONE && act <= GMK_ACT_SIGMOID, GMK_E_UNSUPPORTED);
+  static const int thin_outv = getenv("GMK_THIN_OUTV") ? atoi(getenv("GMK_THIN_OUTV")) : 1;   // 0: the MFMA kernel below (A/B runs)
+  if (thin_outv && gmk_thin_outv_ok(N, Cin, H, W, Cout, ksize, stride))
+    return gmk_launch_conv_thin_outv(x, w, bias, y, dact, N, Cin, H, W, Cout, act, (hipStream_t)stream);
   if (gmk_thin_out_ok(N, Cin, H, W, Cout, ksize, stride))
     return gmk_launch_conv_thin_out(x, w, bias, y, dact, N, Cin, H, W, Cout, ksize, act, (hipStream_t)stream);
   const int KK = ksize * ksize;
