@@ -66,7 +66,8 @@ const char* gmk_strerror(int code);
  * rounding, ~3e-7 of the output scale); GMK_WINO=0 in the environment keeps the implicit GEMM everywhere.
  * Stride-1 3x3 layers with <= 4 channels on the image side and H*W >= 1024 (forward of a Cin <= 4 layer, data gradient
  * of a Cout <= 4 layer) run on the vector ALUs as packed fp32 FMAs (conv_thin_in.hip: bound by the output stream);
- * GMK_THIN_IN=0 keeps the implicit GEMM.
+ * GMK_THIN_IN=0 keeps the implicit GEMM.  The forward of a layer with <= 4 output channels (Cin % 8 == 0, width 16..64)
+ * runs the same way (conv_thin_outv.hip: bound by the input stream; GMK_THIN_OUTV=0: the MFMA kernel of conv_thin_out.hip).
  *
  * gmk_conv2d_fwd: y = act(conv2d(x, w) + bias); if dact != NULL also writes act'(pre-activation)
  *   (the backward pass multiplies by it instead of re-evaluating erf/exp).

@@ -65,10 +65,11 @@ CONV_SHAPES = [
     (2, 21, 32, 32, 3, 3, 1),
     (1, 10, 64, 64, 4, 3, 1),
     (2, 10, 128, 8, 2, 3, 1),
-    # <= 4 output channels, Cin % 16 == 0, widths 16..64: the forward runs conv_thin_outv.hip (packed FMAs, DPP neighbours)
+    # <= 4 output channels, Cin % 8 == 0, widths 16..64: the forward runs conv_thin_outv.hip (packed FMAs, DPP neighbours)
     (3, 32, 16, 16, 4, 3, 1),
     (1, 16, 64, 64, 1, 3, 1),
     (2, 48, 16, 32, 2, 3, 1),
+    (2, 24, 16, 16, 3, 3, 1),
     # channel counts that are not a multiple of the 8-channel K-chunk: pipelined full chunks + masked tail chunk,
     # odd / even numbers of full chunks (zero-weight padding chunk), stride 1 and 2 (dgrad runs the other modes)
     (2, 20, 16, 16, 12, 3, 1),
