@@ -207,6 +207,20 @@ def main():
     import gmk
     gmk.lib()
 
+    # kernel-path choice for this device (gmk/tune.py), on a throw-away replica, before anything is timed
+    from gmk.tune import tune_thin_paths
+    t_model, t_optim, t_sched = build(device)
+    t_x = torch.rand(PER_GPU_BATCH, 3, 32, 32, device=device)
+    t_eps = torch.randn(PER_GPU_BATCH, 256, device=device)
+
+    def t_step():
+        t_model.train_step(t_x, beta=5e-6, eps=t_eps)
+        t_optim.step()
+        t_sched.step()
+
+    tuned = tune_thin_paths(t_step)
+    del t_model, t_optim, t_sched, t_x, t_eps, t_step
+
     model, optim, sched = build(device)
     if world > 1:  # identical replicas: broadcast rank 0's parameters
         broadcast_(optim.flat_param, src=0)
@@ -257,6 +271,8 @@ def main():
                                    "3x32x32, batch 256 per GPU, AdamW+cosine (BASELINE.json configs[1]; configs[2] at N=8)",
                        "global_batch": world * PER_GPU_BATCH, "parallelism": f"dp{world}"},
             "final_losses": {"rec": final_losses[0], "kl": final_losses[1], "total": final_losses[2]},
+            "kernel_paths": {"thin_in,thin_outv": list(tuned["choice"]), "tuned_on_this_device": tuned["tuned"],
+                             "ms_per_step_by_choice": tuned["ms"]},
             "step_mfma_frac": round(ips / world * TRAIN_MFLOP_PER_IMG * 1e6 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
         }
         out["roofline"] = dominant_kernel_roofline(device)

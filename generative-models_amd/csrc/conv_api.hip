@@ -19,6 +19,32 @@ bool gmk_thin_outv_ok(int N, int Cin, int H, int W, int Cout, int ksize, int str
 int gmk_launch_conv_thin_outv(const float* x, const float* w, const float* bias, float* y, float* dact, int N, int Cin,
                               int H, int W, int Cout, int act, hipStream_t s);
 
+// Kernel-path selection of the <= 4-channel-side 3x3 layers (conv_thin_in.hip, conv_thin_outv.hip): -1 = not set yet
+// (first use reads GMK_THIN_IN / GMK_THIN_OUTV, default on); gmk_conv_set_thin_paths overrides (per-device tuning).
+static int g_thin_in = -1, g_thin_outv = -1;
+static int thin_in_mask() {
+  if (g_thin_in < 0) g_thin_in = getenv("GMK_THIN_IN") ? (atoi(getenv("GMK_THIN_IN")) & 3) : 3;   // bit 0: forward, bit 1: data gradient
+  return g_thin_in;
+}
+static int thin_outv_on() {
+  if (g_thin_outv < 0) g_thin_outv = getenv("GMK_THIN_OUTV") ? (atoi(getenv("GMK_THIN_OUTV")) != 0) : 1;
+  return g_thin_outv;
+}
+
+extern "C" int gmk_conv_set_thin_paths(int thin_in, int thin_outv) {
+  GMK_REQUIRE(thin_in <= 3 && thin_outv <= 1, GMK_E_UNSUPPORTED);
+  if (thin_in >= 0) g_thin_in = thin_in;
+  if (thin_outv >= 0) g_thin_outv = thin_outv;
+  return GMK_OK;
+}
+
+extern "C" int gmk_conv_get_thin_paths(int* thin_in, int* thin_outv) {
+  GMK_REQUIRE(thin_in && thin_outv, GMK_E_NULL);
+  *thin_in = thin_in_mask();
+  *thin_outv = thin_outv_on();
+  return GMK_OK;
+}
+
 static int conv_common_checks(int N, int Cin, int H, int W, int Cout, int ksize) {
   if (N <= 0 || Cin <= 0 || Cout <= 0) return GMK_E_SHAPE;
   if (!gmk_is_pow2(H) || !gmk_is_pow2(W) || H < 4 || W < 4 || W > 128) return GMK_E_SHAPE;
@@ -31,8 +57,7 @@ static int dispatch(ConvGeom& g, int ksize, int mode, hipStream_t s) {
   g.dbg = dbg;
   // <= 4 input channels (the image side of the autoencoder): output-stream bound, no GEMM (conv_thin_in.hip); GMK_THIN_IN=0
   // keeps the implicit GEMM (A/B runs)
-  static const int thin_in = getenv("GMK_THIN_IN") ? atoi(getenv("GMK_THIN_IN")) : 3;   // bit 0: forward, bit 1: data gradient
-  if ((thin_in & (g.epi == 0 ? 1 : 2)) && !dbg && gmk_thin_in_ok(g, ksize, mode)) return gmk_launch_conv_thin_in(g, s);
+  if ((thin_in_mask() & (g.epi == 0 ? 1 : 2)) && !dbg && gmk_thin_in_ok(g, ksize, mode)) return gmk_launch_conv_thin_in(g, s);
   // stride-1 3x3 layers whose grid fills the chip (>= GMK_WINO_MIN_BLOCKS blocks of 32 tiles x 64 channels): Winograd
   // F(2x2,3x3) (conv_wino.h).  GMK_WINO: bit 0 = forward, bit 1 = data gradient; 0 keeps the implicit GEMM everywhere
   static const int wino_mask = getenv("GMK_WINO") ? atoi(getenv("GMK_WINO")) : 3;
@@ -54,8 +79,7 @@ extern "C" int gmk_conv2d_fwd(const float* x, const float* w, const float* bias,
   if (rc) return rc;
   GMK_REQUIRE(stride == 1 || stride == 2, GMK_E_UNSUPPORTED);
   GMK_REQUIRE(act >= GMK_ACT_NONE && act <= GMK_ACT_SIGMOID, GMK_E_UNSUPPORTED);
-  static const int thin_outv = getenv("GMK_THIN_OUTV") ? atoi(getenv("GMK_THIN_OUTV")) : 1;   // 0: the MFMA kernel below (A/B runs)
-  if (thin_outv && gmk_thin_outv_ok(N, Cin, H, W, Cout, ksize, stride))
+  if (thin_outv_on() && gmk_thin_outv_ok(N, Cin, H, W, Cout, ksize, stride))
     return gmk_launch_conv_thin_outv(x, w, bias, y, dact, N, Cin, H, W, Cout, act, (hipStream_t)stream);
   if (gmk_thin_out_ok(N, Cin, H, W, Cout, ksize, stride))
     return gmk_launch_conv_thin_out(x, w, bias, y, dact, N, Cin, H, W, Cout, ksize, act, (hipStream_t)stream);

@@ -21,6 +21,8 @@ SIGNATURES = {
     "gmk_version": (_I, []),
     "gmk_stream_wait_stream": (_I, [_P, _P]),
     "gmk_strerror": (C.c_char_p, [_I]),
+    "gmk_conv_set_thin_paths": (_I, [_I, _I]),
+    "gmk_conv_get_thin_paths": (_I, [_P, _P]),
     "gmk_conv2d_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "gmk_conv2d_dgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "gmk_conv2d_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),

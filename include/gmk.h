@@ -58,6 +58,16 @@ int gmk_version(void);
 int gmk_stream_wait_stream(gmk_stream_t waiter, gmk_stream_t on);
 const char* gmk_strerror(int code);
 
+/* gmk_conv_set_thin_paths / gmk_conv_get_thin_paths: which kernels run the 3x3 stride-1 layers with <= 4 channels on
+ *   the image side.  thin_in: bit 0 = forward of a Cin <= 4 layer, bit 1 = data gradient of a Cout <= 4 layer on
+ *   conv_thin_in.hip (else the implicit GEMM); thin_outv: 1 = forward of a Cout <= 4 layer on conv_thin_outv.hip (else
+ *   conv_thin_out.hip).  A negative argument leaves that setting as it is.  Defaults: 3 and 1, or the GMK_THIN_IN /
+ *   GMK_THIN_OUTV environment variables.  Process-wide; call it between launches, not concurrently with them.
+ *   No counterpart in the reference: the faster choice differs between devices of the same model,
+ *   so a host may time its step both ways once and keep the better one (gmk/tune.py). */
+int gmk_conv_set_thin_paths(int thin_in, int thin_outv);
+int gmk_conv_get_thin_paths(int* thin_in, int* thin_outv);
+
 /* ---------------------------------------------------------------- convolutions ----------
  * Implicit-GEMM fp32-MFMA kernels (v_mfma_f32_32x32x2_f32), LDS-staged input patch + weights.
  * ksize in {3,5}, padding (ksize-1)/2, stride in {1,2}.

@@ -336,3 +336,31 @@ def test_one_launch_loss_matches_two_launch_form(B, variational):
         if variational and rep != 1:
             assert torch.equal(got[2], ref[2])
         assert got[2] is None or rep != 1
+
+
+def test_thin_path_switch_agrees():
+    """gmk_conv_set_thin_paths: both kernel paths of the 3-channel-side layers give the same results (fp32 rounding)."""
+    from gmk import ops, tune
+    x = T("tpx", (4, 3, 32, 32)).to(dev())
+    w = (T("tpw", (64, 3, 3, 3)) / np.sqrt(27)).to(dev())
+    b = T("tpb", (64,)).to(dev())
+    h = T("tph", (4, 64, 32, 32)).to(dev())
+    w3 = (T("tpw3", (3, 64, 3, 3)) / np.sqrt(576)).to(dev())
+    b3 = T("tpb3", (3,)).to(dev())
+    dy3 = T("tpd", (4, 3, 32, 32)).to(dev())
+    before = tune.get_thin_paths()
+    outs = []
+    try:
+        for choice in ((0, 0), (3, 1)):
+            tune.set_thin_paths(*choice)
+            assert tune.get_thin_paths() == choice
+            y, d = ops.conv2d_fwd(x, w, b, act="gelu", want_dact=True)
+            y3 = ops.conv2d_fwd(h, w3, b3)
+            dx = ops.conv2d_dgrad(dy3, w3, (4, 64, 32, 32), 1, dact_in=h)
+            outs.append([t.clone() for t in (y, d, y3, dx)])
+        tune.set_thin_paths(-1, -1)   # negative: unchanged
+        assert tune.get_thin_paths() == (3, 1)
+    finally:
+        tune.set_thin_paths(*before)
+    for a, c, name in zip(outs[0], outs[1], ("y", "dact", "y3", "dx")):
+        close(c, a.double().cpu(), tol=1e-5, name=name)

@@ -5,7 +5,7 @@ def load(p):
 a, b = load(sys.argv[1]), load(sys.argv[2])
 ta = tb = 0.0
 for k in sorted(a, key=lambda k: -a[k][0] * a[k][1]):
-    if k in b and a[k][0] == b[k][0] and a[k][0] >= 20:
+    if k in b and min(a[k][0], b[k][0]) >= 20:
         print("%-60s %4d  %8.1f %8.1f  %+6.1f%%" % (k, a[k][0], a[k][1], b[k][1], (b[k][1] / a[k][1] - 1) * 100))
         ta += a[k][0] * a[k][1]; tb += b[k][0] * b[k][1]
 print("total of common kernels: %.0f -> %.0f us (%+.1f%%)" % (ta, tb, (tb / ta - 1) * 100))
