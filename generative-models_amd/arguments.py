@@ -37,4 +37,7 @@ def get_args_parser(add_help=True):
     a("--no_upsample", dest="no_upsample", help="don't use nn.Upsample for upsampling, use deconv", action="store_true")
     a("--interpolation", default="nearest", type=str, help="upsample interpolation mode in the decoder, "
       "'nearest', 'linear', 'bilinear', 'bicubic' and 'trilinear'")
+    # not in the reference: time the train step with both kernel paths of the 3-channel-side layers on this device
+    # and keep the faster one (gmk/tune.py); off by default so that runs stay bitwise comparable across devices
+    a("--tune_kernels", dest="tune_kernels", help="per-device kernel-path tuning before training", action="store_true")
     return parser

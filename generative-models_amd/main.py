@@ -158,6 +158,25 @@ def main(args):
         for p in model.parameters():
             from gmk.parallel import broadcast_
             broadcast_(p.data, src=0)
+    if args.train and getattr(args, "tune_kernels", False):
+        # kernel-path choice for this device on a throw-away replica and synthetic input (gmk/tune.py): the real
+        # parameters, the optimizer state and the data order are untouched
+        from gmk.tune import tune_thin_paths
+        t_model = Autoencoder(variational=args.variational, latent_size=args.latent_size, num_channels=args.num_channels,
+                              kernel_size=args.kernel_size, act=args.act_fn, sigmoid=args.sigmoid,
+                              interpolation=args.interpolation, no_pool=args.no_pool, no_upsample=args.no_upsample,
+                              device=device, debug=False).to(device)
+        t_optim = FusedAdamW(t_model.parameters(), lr=args.lr, weight_decay=args.wd)
+        t_image = torch.rand(args.train_batch_size, 3, 32, 32, device=device)
+
+        def t_step():
+            t_model.train_step(t_image, beta=beta if args.variational else 0.0, mse_prior=args.mse)
+            t_optim.step()
+
+        tuned = tune_thin_paths(t_step)
+        if rank == 0:
+            print(f'\n\nKernel paths on this device (thin_in, thin_outv): {tuned["choice"]}  {tuned["ms"]}')
+        del t_model, t_optim, t_image, t_step
     optim = FusedAdamW(model.parameters(), lr=args.lr, weight_decay=args.wd)
     lr_scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optim, T_max=args.epochs * len(train_dataloader))
     reducer = GradReducer(model, optim) if world > 1 else None

@@ -364,3 +364,24 @@ def test_thin_path_switch_agrees():
         tune.set_thin_paths(*before)
     for a, c, name in zip(outs[0], outs[1], ("y", "dact", "y3", "dx")):
         close(c, a.double().cpu(), tol=1e-5, name=name)
+
+
+def test_tune_thin_paths_picks_and_applies_a_candidate(monkeypatch):
+    from gmk import ops, tune
+    for k in ("GMK_TUNE", "GMK_THIN_IN", "GMK_THIN_OUTV"):
+        monkeypatch.delenv(k, raising=False)
+    x = T("ttx", (8, 3, 32, 32)).to(dev())
+    w = (T("ttw", (64, 3, 3, 3)) / np.sqrt(27)).to(dev())
+    b = T("ttb", (64,)).to(dev())
+    before = tune.get_thin_paths()
+    try:
+        r = tune.tune_thin_paths(lambda: ops.conv2d_fwd(x, w, b, act="gelu", want_dact=True), steps=5, rounds=2, warmup=2)
+        assert r["tuned"] and tuple(r["choice"]) in tune.CANDIDATES
+        assert tune.get_thin_paths() == tuple(r["choice"])
+        assert set(r["ms"]) == {"3,1", "0,0"} and all(v > 0 for v in r["ms"].values())
+        monkeypatch.setenv("GMK_TUNE", "0")
+        tune.set_thin_paths(3, 1)
+        r = tune.tune_thin_paths(lambda: None)
+        assert not r["tuned"] and tuple(r["choice"]) == (3, 1)
+    finally:
+        tune.set_thin_paths(*before)
