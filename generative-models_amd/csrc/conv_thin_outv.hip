@@ -38,7 +38,12 @@ __global__ __launch_bounds__(256) void conv_thin_outv_kernel(const ThinOutVGeom 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the channel-range guards below are uniform branches
   const int W = g.W, H = g.H, HW = 1 << g.lgHW;
   const int tiles = HW >> 8;
-  const int n = blockIdx.x / tiles, px0 = (blockIdx.x % tiles) << 8;
+  // Blocks go round-robin over the 8 XCDs (one L2 each): hand XCD x the tiles [x nb/8, (x+1) nb/8), so that the halo rows
+  // a tile shares with its neighbours (2 of 8 rows at 32x32: 25 % more HBM reads under PMC without this) hit in that L2
+  int b = blockIdx.x;
+  const int nb = gridDim.x;
+  if ((nb & 7) == 0) b = (b & 7) * (nb >> 3) + (b >> 3);
+  const int n = b / tiles, px0 = (b % tiles) << 8;
 
   const int p = px0 + 4 * lane, r = p >> g.lgW, x0 = p & (W - 1);
   const bool up = r > 0, down = r < H - 1;
