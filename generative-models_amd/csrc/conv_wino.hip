@@ -34,7 +34,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvGeom g) {
   const int l15 = lane & 15, kq = lane >> 4;
   const int W = g.IW, H = g.IH, HW = H * W;
   const int lgW = g.lgBW, lgHW = g.lgBHW, lgTW = lgW - 1, lgTHW = lgHW - 2, TW = W >> 1;
-  const long long T0 = (long long)blockIdx.x * WINO_TB;
+  // blocks go round-robin over the 8 XCDs: XCD x takes the tile groups [x nb/8, (x+1) nb/8), so the halo rows shared by
+  // neighbouring groups of one image are read from HBM once (one L2 per XCD)
+  int bx = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
+  const long long T0 = (long long)bx * WINO_TB;
   const int m0 = blockIdx.y * WINO_MB;
   const __amdgpu_buffer_rsrc_t rx = gmk_make_rsrc(g.x, (long long)g.N * g.C * HW * 4);
 
