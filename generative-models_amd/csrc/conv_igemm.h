@@ -56,7 +56,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WP, wp = wave % WP;
   const int h = lane >> 5, j = lane & 31;
-  const long long p0 = (long long)blockIdx.x * PT;
+  // Blocks go round-robin over the 8 XCDs (one L2 each; linear block id = x + y gridDim.x): XCD k takes the position
+  // tiles [k nb/8, (k+1) nb/8), so the halo rows that neighbouring tiles of one image share are fetched from HBM once
+  int bxr = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bxr = (bxr & 7) * (gridDim.x >> 3) + (bxr >> 3);
+  const long long p0 = (long long)bxr * PT;
   const int m0 = blockIdx.y * MB;
   const int BHW = 1 << g.lgBHW;
   const int PR = g.PR, PC = g.PC, PS = g.PS;
