@@ -3,7 +3,9 @@
 //   conv fwd s1 -> MODE0, s2 -> MODE1 ; conv dgrad s1 -> MODE0 with flipped taps and [c][m] weights,
 //   s2 -> MODE2 ; deconv fwd -> MODE2 ; deconv dgrad -> MODE1.
 #include "conv_wino.h"
+#include "plan.h"
 #include <stdlib.h>
+#include <mutex>
 
 // conv_thin_out.hip: forward of stride-1 convs with <= 8 output channels (dec.conv3)
 bool gmk_thin_out_ok(int N, int Cin, int H, int W, int Cout, int ksize, int stride);
@@ -19,22 +21,38 @@ bool gmk_thin_outv_ok(int N, int Cin, int H, int W, int Cout, int ksize, int str
 int gmk_launch_conv_thin_outv(const float* x, const float* w, const float* bias, float* y, float* dact, int N, int Cin,
                               int H, int W, int Cout, int act, hipStream_t s);
 
-// Kernel-path selection of the <= 4-channel-side 3x3 layers (conv_thin_in.hip, conv_thin_outv.hip): -1 = not set yet
-// (first use reads GMK_THIN_IN / GMK_THIN_OUTV, default on); gmk_conv_set_thin_paths overrides (per-device tuning).
-static int g_thin_in = -1, g_thin_outv = -1;
-static int thin_in_mask() {
-  if (g_thin_in < 0) g_thin_in = getenv("GMK_THIN_IN") ? (atoi(getenv("GMK_THIN_IN")) & 3) : 3;   // bit 0: forward, bit 1: data gradient
-  return g_thin_in;
+// Kernel-path selection of the <= 4-channel-side 3x3 layers (conv_thin_in.hip, conv_thin_outv.hip).  This is the one piece
+// of mutable state behind the conv entry points, and it is PER DEVICE (the faster choice differs between devices of the
+// same model, gmk/tune.py): one atomic word per device, -1 = not set yet (first use reads GMK_THIN_IN / GMK_THIN_OUTV,
+// default on), read once per launch with the launching thread's current device; gmk_conv_set_thin_paths sets the
+// current device's word.  Atomic, so a setter racing a launch on another thread yields one of the two valid choices.
+#include <atomic>
+#define GMK_THIN_MAX_DEVICES 64
+static std::atomic<int> g_thin_in[GMK_THIN_MAX_DEVICES], g_thin_outv[GMK_THIN_MAX_DEVICES];
+static std::atomic<bool> g_thin_init{false};
+static int thin_dev() {
+  if (!g_thin_init.load(std::memory_order_acquire)) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!g_thin_init.load(std::memory_order_relaxed)) {
+      const int in0 = getenv("GMK_THIN_IN") ? (atoi(getenv("GMK_THIN_IN")) & 3) : 3;   // bit 0: forward, bit 1: data gradient
+      const int ov0 = getenv("GMK_THIN_OUTV") ? (atoi(getenv("GMK_THIN_OUTV")) != 0) : 1;
+      for (int d = 0; d < GMK_THIN_MAX_DEVICES; ++d) { g_thin_in[d].store(in0); g_thin_outv[d].store(ov0); }
+      g_thin_init.store(true, std::memory_order_release);
+    }
+  }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GMK_THIN_MAX_DEVICES) dev = 0;
+  return dev;
 }
-static int thin_outv_on() {
-  if (g_thin_outv < 0) g_thin_outv = getenv("GMK_THIN_OUTV") ? (atoi(getenv("GMK_THIN_OUTV")) != 0) : 1;
-  return g_thin_outv;
-}
+static int thin_in_mask() { const int d = thin_dev(); return g_thin_in[d].load(std::memory_order_relaxed); }
+static int thin_outv_on() { const int d = thin_dev(); return g_thin_outv[d].load(std::memory_order_relaxed); }
 
 extern "C" int gmk_conv_set_thin_paths(int thin_in, int thin_outv) {
   GMK_REQUIRE(thin_in <= 3 && thin_outv <= 1, GMK_E_UNSUPPORTED);
-  if (thin_in >= 0) g_thin_in = thin_in;
-  if (thin_outv >= 0) g_thin_outv = thin_outv;
+  const int d = thin_dev();
+  if (thin_in >= 0) g_thin_in[d].store(thin_in);
+  if (thin_outv >= 0) g_thin_outv[d].store(thin_outv);
   return GMK_OK;
 }
 
@@ -63,7 +81,7 @@ static int dispatch(ConvGeom& g, int ksize, int mode, hipStream_t s) {
   static const int wino_mask = getenv("GMK_WINO") ? atoi(getenv("GMK_WINO")) : 3;
   const int wino = wino_mask & (g.epi == 0 ? 1 : 2);
   static const int minb = getenv("GMK_WINO_MIN_BLOCKS") ? atoi(getenv("GMK_WINO_MIN_BLOCKS")) : 256;
-  if (wino && !dbg && gmk_wino_ok(g, ksize, mode) &&
+  if (wino && !dbg && gmk_wino_ok(g, ksize, mode) && (g.flip || gmk_wino_fwd_ready()) &&
       ((long long)g.N * g.IH * g.IW / 4 / WINO_TB) * ((g.M + WINO_MB - 1) / WINO_MB) >= minb) {
     static const int wdbg = getenv("GMK_WINO_DBG") ? atoi(getenv("GMK_WINO_DBG")) : 0;   // profiling ablations only
     g.dbg = wdbg;
@@ -74,6 +92,7 @@ static int dispatch(ConvGeom& g, int ksize, int mode, hipStream_t s) {
 
 extern "C" int gmk_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* dact, int N,
                               int Cin, int H, int W, int Cout, int ksize, int stride, int act, gmk_stream_t stream) {
+  GMK_PLAN_HOOK(gmk_conv2d_fwd, x, w, bias, y, dact, N, Cin, H, W, Cout, ksize, stride, act, stream);
   GMK_REQUIRE(x && w && y, GMK_E_NULL);
   int rc = conv_common_checks(N, Cin, H, W, Cout, ksize);
   if (rc) return rc;
@@ -96,6 +115,7 @@ extern "C" int gmk_conv2d_fwd(const float* x, const float* w, const float* bias,
 
 extern "C" int gmk_conv2d_dgrad(const float* dy, const float* w, const float* dact_in, float* dx, int N, int Cin,
                                 int H, int W, int Cout, int ksize, int stride, gmk_stream_t stream) {
+  GMK_PLAN_HOOK(gmk_conv2d_dgrad, dy, w, dact_in, dx, N, Cin, H, W, Cout, ksize, stride, stream);
   GMK_REQUIRE(dy && w && dx, GMK_E_NULL);
   int rc = conv_common_checks(N, Cin, H, W, Cout, ksize);
   if (rc) return rc;
@@ -113,6 +133,7 @@ extern "C" int gmk_conv2d_dgrad(const float* dy, const float* w, const float* da
 
 extern "C" int gmk_deconv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* dact, int N,
                                 int Cin, int H, int W, int Cout, int ksize, int act, gmk_stream_t stream) {
+  GMK_PLAN_HOOK(gmk_deconv2d_fwd, x, w, bias, y, dact, N, Cin, H, W, Cout, ksize, act, stream);
   GMK_REQUIRE(x && w && y, GMK_E_NULL);
   int rc = conv_common_checks(N, Cin, H, W, Cout, ksize);
   if (rc) return rc;
@@ -131,6 +152,7 @@ extern "C" int gmk_deconv2d_fwd(const float* x, const float* w, const float* bia
 
 extern "C" int gmk_deconv2d_dgrad(const float* dy, const float* w, const float* dact_in, float* dx, int N, int Cin,
                                   int H, int W, int Cout, int ksize, gmk_stream_t stream) {
+  GMK_PLAN_HOOK(gmk_deconv2d_dgrad, dy, w, dact_in, dx, N, Cin, H, W, Cout, ksize, stream);
   GMK_REQUIRE(dy && w && dx, GMK_E_NULL);
   int rc = conv_common_checks(N, Cin, H, W, Cout, ksize);
   if (rc) return rc;

@@ -404,7 +404,7 @@ static int gmk_launch_conv_impl(ConvGeom& g, int mode, hipStream_t s) {
     auto kern = (nslot <= GMK_NS_LO(MODE_)) ? conv_igemm_kernel<MODE_, KS, CK_, WM_, MT_, GMK_NS_LO(MODE_)> \
                                             : conv_igemm_kernel<MODE_, KS, CK_, WM_, MT_, GMK_NS_HI(MODE_)>; \
     if (lds > 64 * 1024) {                                                                                 \
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipError_t e = gmk_ensure_dyn_lds((const void*)kern, (int)lds); \
       if (e != hipSuccess) return (int)e;                                                                  \
     }                                                                                                      \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, g);                                                  \

@@ -129,7 +129,7 @@ static int launch_thin_out(const ThinOutGeom& g, hipStream_t s) {
   if (lds > 160 * 1024) return GMK_E_SHAPE;
   auto kern = conv_thin_out_kernel<KS, NB>;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = gmk_ensure_dyn_lds((const void*)kern, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   hipLaunchKernelGGL(kern, dim3(g.N * (g.H / g.TR)), dim3(256), lds, s, g);

@@ -150,6 +150,7 @@ bool gmk_thin_outv_ok(int N, int Cin, int H, int W, int Cout, int ksize, int str
   if (Cout > 4 || Cin < 16 || Cin % (8 * THIN_OUTV_TG) != 0) return false;   // a wave takes Cin / 4 channels in double groups
   if (!gmk_is_pow2(H) || !gmk_is_pow2(W) || W < 16 || W > 64 || (long long)H * W < 256) return false;
   if ((long long)N * (H * W / 256) > 0x7FFFFFFFll) return false;
+  if (sizeof(float) * (size_t)Cin * 36 > 64 * 1024) return false;   // the weight table must fit the default LDS window (Cin <= 455): wider layers take conv_thin_out / the implicit GEMM
   return true;
 }
 

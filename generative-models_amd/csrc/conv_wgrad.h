@@ -426,7 +426,7 @@ static int gmk_launch_wgrad_impl(WgradGeom& g, int sb, float* dw, float* dbias, 
   do {                                                                                                             \
     auto kern = conv_wgrad_kernel<KS, SB_, NT, LGSW_>;                                                             \
     if (lds > 64 * 1024) {                                                                                         \
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipError_t e = gmk_ensure_dyn_lds((const void*)kern, (int)lds); \
       if (e != hipSuccess) return (int)e;                                                                          \
     }                                                                                                              \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, g);                                                          \

@@ -10,7 +10,7 @@ static int launch16(WgradGeom& g, float* dw, float* dbias, hipStream_t s) {
   auto kern = g.bias_mode == 0 ? conv_wgrad16_kernel<SB, LGSW, 0>
             : g.bias_mode == 1 ? conv_wgrad16_kernel<SB, LGSW, 1> : conv_wgrad16_kernel<SB, LGSW, 2>;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = gmk_ensure_dyn_lds((const void*)kern, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   dim3 grid(g.G, g.csT * g.cbT);

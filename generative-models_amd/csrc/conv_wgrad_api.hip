@@ -1,5 +1,6 @@
 // conv_wgrad_api.hip -- C-ABI entry points for conv / deconv weight + bias gradients.
 #include "conv_wgrad.h"
+#include "plan.h"
 #include "conv_wgrad16.h"
 #include "conv_wgrad_thin.h"
 
@@ -72,6 +73,7 @@ static int wgrad_run(const float* small, const float* big, float* dw, float* dbi
 extern "C" int gmk_conv2d_wgrad(const float* dy, const float* x, float* dw, float* dbias, int N, int Cin, int H,
                                 int W, int Cout, int ksize, int stride, void* ws, size_t ws_bytes,
                                 gmk_stream_t stream) {
+  GMK_PLAN_HOOK(gmk_conv2d_wgrad, dy, x, dw, dbias, N, Cin, H, W, Cout, ksize, stride, ws, ws_bytes, stream);
   GMK_REQUIRE(dy && x && dw && ws, GMK_E_NULL);
   GMK_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2), GMK_E_SHAPE);
   ThinGeom t{};
@@ -87,6 +89,7 @@ extern "C" int gmk_conv2d_wgrad(const float* dy, const float* x, float* dw, floa
 
 extern "C" int gmk_deconv2d_wgrad(const float* dy, const float* x, float* dw, float* dbias, int N, int Cin, int H,
                                   int W, int Cout, int ksize, void* ws, size_t ws_bytes, gmk_stream_t stream) {
+  GMK_PLAN_HOOK(gmk_deconv2d_wgrad, dy, x, dw, dbias, N, Cin, H, W, Cout, ksize, ws, ws_bytes, stream);
   GMK_REQUIRE(dy && x && dw && ws, GMK_E_NULL);
   GMK_REQUIRE(N > 0 && Cin > 0 && Cout > 0, GMK_E_SHAPE);
   return wgrad_run(x, dy, dw, dbias, 2, N, Cin, Cout, H, W, ksize, 2, ws, ws_bytes, (hipStream_t)stream);

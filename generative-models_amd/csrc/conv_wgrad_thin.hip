@@ -9,7 +9,7 @@ static int launch_thin(ThinGeom& g, float* dw, float* dbias, hipStream_t s) {
   if (lds < red) lds = red;
   if (lds > 160 * 1024) return GMK_E_SHAPE;
   auto kern = conv_wgrad_thin_kernel<KS, NB>;
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = gmk_ensure_dyn_lds((const void*)kern, (int)lds);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kern, dim3(g.G, g.nWT), dim3(GMK_THIN_THREADS), lds, s, g);
   e = hipGetLastError();

@@ -24,3 +24,4 @@ static inline bool gmk_wino_ok(const ConvGeom& g, int ksize, int mode) {
 }
 
 int gmk_launch_conv_wino(ConvGeom& g, hipStream_t s);
+bool gmk_wino_fwd_ready();   // forward kernel's 66 KiB LDS limit raised on the current device (once); false = use the implicit GEMM

@@ -299,15 +299,31 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvGeom g) {
 }
 
 
+// The forward kernel needs 66 KiB of dynamic LDS: the limit is raised once per device (not on every launch); if the
+// runtime refuses, the dispatcher keeps the layer on the implicit GEMM instead of failing the call.
+#include <mutex>
+bool gmk_wino_fwd_ready() {
+  static std::mutex mu;
+  static signed char state[64];   // per device: 0 = not tried, 1 = ok, -1 = refused
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  if (state[dev] == 0) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       WINO_LDS_FLOATS(0) * 4);
+    if (e != hipSuccess) (void)hipGetLastError();   // clear the sticky error: the caller falls back
+    state[dev] = e == hipSuccess ? 1 : -1;
+  }
+  return state[dev] > 0;
+}
+
 int gmk_launch_conv_wino(ConvGeom& g, hipStream_t s) {
   const long long tiles = (long long)g.N * g.IH * g.IW / 4;
   dim3 grid((unsigned)(tiles / WINO_TB), (unsigned)((g.M + WINO_MB - 1) / WINO_MB));
   if (g.flip) {
     hipLaunchKernelGGL(conv_wino_kernel<true>, grid, dim3(256), WINO_LDS_FLOATS(1) * 4, s, g);
   } else {
-    constexpr int lds = WINO_LDS_FLOATS(0) * 4;   // 66 KiB: above the 64 KiB default
-    hipError_t ea = hipFuncSetAttribute((const void*)conv_wino_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (ea != hipSuccess) return (int)ea;
+    constexpr int lds = WINO_LDS_FLOATS(0) * 4;   // 66 KiB: above the 64 KiB default (gmk_wino_fwd_ready raised the limit)
     hipLaunchKernelGGL(conv_wino_kernel<false>, grid, dim3(256), lds, s, g);
   }
   hipError_t e = hipGetLastError();

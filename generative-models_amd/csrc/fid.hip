@@ -239,8 +239,14 @@ static void gram128_plan(long long n, int D, int* splits, long long* per) {
 }
 
 extern "C" size_t gmk_gram_workspace_bytes(int64_t n, int D) {
+  // the larger of the two kernels' plans: gmk_gram_accumulate falls back to the 64-tile kernel (gram_splits slabs) when X
+  // is not 16-byte aligned or GMK_GRAM64 is set, and for D >= 512 that is more slabs than the 128-tile plan has
   int splits = gram_splits(n);
-  if (D % 4 == 0) { long long per; gram128_plan(n, D, &splits, &per); }
+  if (D % 4 == 0) {
+    int s128; long long per;
+    gram128_plan(n, D, &s128, &per);
+    if (s128 > splits) splits = s128;
+  }
   return sizeof(double) * (size_t)splits * ((size_t)D * D + D) + 256;
 }
 

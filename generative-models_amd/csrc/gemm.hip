@@ -4,6 +4,7 @@
 // 64x64 block tile, 4 waves (2x2) of one 32x32 accumulator, K-chunk 32 staged in LDS.
 // Small-M shapes (M = batch) are split along K into fp32 slabs and reduced in a fixed order.
 #include "gmk_common.h"
+#include "plan.h"
 
 #define GT 64
 #define GK 32
@@ -448,6 +449,7 @@ static int run_gemm(GemmArgs g, void* ws, size_t ws_bytes, hipStream_t s) {
 
 extern "C" int gmk_linear_fwd(const float* x, const float* w, const float* bias, float* y, float* dact, int M,
                               int K, int N, int act, void* ws, size_t ws_bytes, gmk_stream_t stream) {
+  GMK_PLAN_HOOK(gmk_linear_fwd, x, w, bias, y, dact, M, K, N, act, ws, ws_bytes, stream);
   GMK_REQUIRE(x && w && y, GMK_E_NULL);
   GMK_REQUIRE(M > 0 && K > 0 && N > 0, GMK_E_SHAPE);
   GMK_REQUIRE(act >= GMK_ACT_NONE && act <= GMK_ACT_SIGMOID, GMK_E_UNSUPPORTED);
@@ -460,6 +462,7 @@ extern "C" int gmk_linear_fwd(const float* x, const float* w, const float* bias,
 
 extern "C" int gmk_linear_dgrad(const float* dy, const float* w, const float* dact_in, float* dx, int M, int K,
                                 int N, void* ws, size_t ws_bytes, gmk_stream_t stream) {
+  GMK_PLAN_HOOK(gmk_linear_dgrad, dy, w, dact_in, dx, M, K, N, ws, ws_bytes, stream);
   GMK_REQUIRE(dy && w && dx, GMK_E_NULL);
   GMK_REQUIRE(M > 0 && K > 0 && N > 0, GMK_E_SHAPE);
   GemmArgs g{};
@@ -471,6 +474,7 @@ extern "C" int gmk_linear_dgrad(const float* dy, const float* w, const float* da
 
 extern "C" int gmk_linear_wgrad(const float* dy, const float* x, float* dw, float* dbias, int M, int K, int N,
                                 void* ws, size_t ws_bytes, gmk_stream_t stream) {
+  GMK_PLAN_HOOK(gmk_linear_wgrad, dy, x, dw, dbias, M, K, N, ws, ws_bytes, stream);
   GMK_REQUIRE(dy && x && dw, GMK_E_NULL);
   GMK_REQUIRE(M > 0 && K > 0 && N > 0, GMK_E_SHAPE);
   GemmArgs g{};
@@ -485,6 +489,7 @@ extern "C" int gmk_linear_wgrad(const float* dy, const float* x, float* dw, floa
 // run in the epilogue of the split-K reduction): stats (M, 2L) and z (M, L) out.  N = 2L.
 extern "C" int gmk_linear_fwd_reparam(const float* x, const float* w, const float* bias, const float* eps, float* stats,
                                       float* z, int M, int K, int N, void* ws, size_t ws_bytes, gmk_stream_t stream) {
+  GMK_PLAN_HOOK(gmk_linear_fwd_reparam, x, w, bias, eps, stats, z, M, K, N, ws, ws_bytes, stream);
   GMK_REQUIRE(x && w && eps && stats && z, GMK_E_NULL);
   GMK_REQUIRE(M > 0 && K > 0 && N > 0 && N % 2 == 0, GMK_E_SHAPE);
   GemmArgs g{};
@@ -499,6 +504,7 @@ extern "C" int gmk_linear_fwd_reparam(const float* x, const float* w, const floa
 extern "C" int gmk_linear_dgrad_reparam(const float* dy, const float* w, const float* stats, const float* eps,
                                         float* dstats, int M, int K, int N, float kl_scale, int mse_prior, void* ws,
                                         size_t ws_bytes, gmk_stream_t stream) {
+  GMK_PLAN_HOOK(gmk_linear_dgrad_reparam, dy, w, stats, eps, dstats, M, K, N, kl_scale, mse_prior, ws, ws_bytes, stream);
   GMK_REQUIRE(dy && w && stats && eps && dstats, GMK_E_NULL);
   GMK_REQUIRE(M > 0 && K > 0 && N > 0, GMK_E_SHAPE);
   GemmArgs g{};

@@ -1,5 +1,6 @@
 // gmk_api.hip -- version / error strings.
 #include "gmk_common.h"
+#include "plan.h"
 
 extern "C" int gmk_version(void) { return 1; }
 
@@ -11,6 +12,7 @@ extern "C" const char* gmk_strerror(int code) {
     case GMK_E_UNSUPPORTED: return "gmk: unsupported option";
     case GMK_E_WORKSPACE: return "gmk: workspace too small";
     case GMK_E_NULL: return "gmk: required pointer is NULL";
+    case GMK_E_STATE: return "gmk: call out of order (plan recording already active / not active / still recording)";
     case GMK_E_TOO_LARGE: return "gmk: input exceeds the stated maximum of this allocation-free entry point";
     default: break;
   }
@@ -26,23 +28,31 @@ extern "C" const char* gmk_strerror(int code) {
 #define GMK_EVENT_RING 64
 #define GMK_MAX_DEVICES 16
 extern "C" int gmk_stream_wait_stream(gmk_stream_t waiter, gmk_stream_t on) {
+  GMK_PLAN_HOOK(gmk_stream_wait_stream, waiter, on);
   static hipEvent_t ring[GMK_MAX_DEVICES][GMK_EVENT_RING];
   static bool made[GMK_MAX_DEVICES];
   static unsigned next[GMK_MAX_DEVICES];
   static std::mutex mu;
+  // the event ring of the device that owns `on` (an event must be recorded on a stream of its own device); the NULL
+  // stream belongs to the current device
   int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
+  hipError_t e = on ? hipStreamGetDevice((hipStream_t)on, &dev) : hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
   GMK_REQUIRE(dev >= 0 && dev < GMK_MAX_DEVICES, GMK_E_UNSUPPORTED);
   hipEvent_t ev;
   {
     std::lock_guard<std::mutex> lock(mu);
     if (!made[dev]) {
+      int cur = 0;
+      e = hipGetDevice(&cur);
+      if (e != hipSuccess) return (int)e;
+      if (cur != dev && (e = hipSetDevice(dev)) != hipSuccess) return (int)e;   // events are created on the current device
       for (int i = 0; i < GMK_EVENT_RING; ++i) {
         e = hipEventCreateWithFlags(&ring[dev][i], hipEventDisableTiming);
         if (e != hipSuccess) return (int)e;
       }
       made[dev] = true;
+      if (cur != dev && (e = hipSetDevice(cur)) != hipSuccess) return (int)e;
     }
     ev = ring[dev][next[dev]++ % GMK_EVENT_RING];
   }
@@ -50,4 +60,21 @@ extern "C" int gmk_stream_wait_stream(gmk_stream_t waiter, gmk_stream_t on) {
   if (e != hipSuccess) return (int)e;
   e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
   return e == hipSuccess ? GMK_OK : (int)e;
+}
+
+// hipFuncSetAttribute costs ~2 us of host time; the launchers of kernels with more than 64 KiB of dynamic LDS used to call
+// it on every launch.  One table entry per (kernel, device): the largest limit set so far.
+#include <map>
+hipError_t gmk_ensure_dyn_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  int& have = done[std::make_pair(kernel, dev)];
+  if (have >= bytes) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) have = bytes;
+  return e;
 }

@@ -21,6 +21,10 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
     if (!(cond)) return (code); \
   } while (0)
 
+// Raises a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) once per (kernel, device, size)
+// instead of on every launch (gmk_api.hip); returns hipSuccess or the runtime's error.
+hipError_t gmk_ensure_dyn_lds(const void* kernel, int bytes);
+
 static inline bool gmk_is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int gmk_ilog2(int64_t v) {
   int l = 0;

@@ -3,6 +3,7 @@
 // write dpre, read stats, write dstats.  One pass, float4 per lane, wave64 shuffle reduction,
 // per-block fp64 partials, fixed-order 1-block finalize (deterministic).
 #include "gmk_common.h"
+#include "plan.h"
 #include <stdlib.h>
 #include <mutex>
 
@@ -195,6 +196,7 @@ static int vae_loss_launch(const float* pre, const float* image, const float* st
 extern "C" int gmk_vae_loss_fwd_bwd(const float* pre, const float* image, const float* stats, float* recon_out,
                                     float* dpre, float* dstats, float* losses, int64_t B, int64_t chw, int64_t L,
                                     float beta, int flags, void* ws, size_t ws_bytes, gmk_stream_t stream) {
+  GMK_PLAN_HOOK(gmk_vae_loss_fwd_bwd, pre, image, stats, recon_out, dpre, dstats, losses, B, chw, L, beta, flags, ws, ws_bytes, stream);
   return vae_loss_launch(pre, image, stats, recon_out, dpre, dstats, losses, B, chw, L, beta, flags, ws, ws_bytes,
                          stream, true);
 }
@@ -205,6 +207,7 @@ extern "C" int gmk_vae_loss_fwd_bwd_fused(const float* pre, const float* image, 
                                           float* dpre, float* dstats, float* losses, int64_t B, int64_t chw, int64_t L,
                                           float beta, int flags, void* ws, size_t ws_bytes, void* sync,
                                           gmk_stream_t stream) {
+  GMK_PLAN_HOOK(gmk_vae_loss_fwd_bwd_fused, pre, image, stats, recon_out, dpre, dstats, losses, B, chw, L, beta, flags, ws, ws_bytes, sync, stream);
   GMK_REQUIRE(sync, GMK_E_NULL);
   GMK_REQUIRE((((uintptr_t)sync) & 255u) == 0, GMK_E_ALIGN);
   return vae_loss_launch(pre, image, stats, recon_out, dpre, dstats, losses, B, chw, L, beta, flags, ws, ws_bytes,
@@ -214,6 +217,7 @@ extern "C" int gmk_vae_loss_fwd_bwd_fused(const float* pre, const float* image, 
 extern "C" int gmk_vae_loss_eval(const float* pre, const float* image, const float* stats, float* recon_out,
                                  float* out5, int64_t B, int64_t chw, int64_t L, float beta, int flags, void* ws,
                                  size_t ws_bytes, gmk_stream_t stream) {
+  GMK_PLAN_HOOK(gmk_vae_loss_eval, pre, image, stats, recon_out, out5, B, chw, L, beta, flags, ws, ws_bytes, stream);
   return vae_loss_launch(pre, image, stats, recon_out, nullptr, nullptr, out5, B, chw, L, beta, flags, ws, ws_bytes,
                          stream, false);
 }
@@ -290,6 +294,7 @@ __global__ __launch_bounds__(256) void reparam_bwd_kernel(const float* __restric
 
 extern "C" int gmk_reparam_fwd(const float* stats, const float* eps, float* z, int64_t B, int64_t L,
                                gmk_stream_t stream) {
+  GMK_PLAN_HOOK(gmk_reparam_fwd, stats, eps, z, B, L, stream);
   GMK_REQUIRE(stats && eps && z, GMK_E_NULL);
   GMK_REQUIRE(B > 0 && L > 0, GMK_E_SHAPE);
   int64_t n = B * L;
@@ -301,6 +306,7 @@ extern "C" int gmk_reparam_fwd(const float* stats, const float* eps, float* z, i
 
 extern "C" int gmk_reparam_bwd(const float* dz, const float* stats, const float* eps, float* dstats, int64_t B,
                                int64_t L, int accumulate, gmk_stream_t stream) {
+  GMK_PLAN_HOOK(gmk_reparam_bwd, dz, stats, eps, dstats, B, L, accumulate, stream);
   GMK_REQUIRE(dz && stats && eps && dstats, GMK_E_NULL);
   GMK_REQUIRE(B > 0 && L > 0, GMK_E_SHAPE);
   int64_t n = B * L;

@@ -4,6 +4,7 @@
 // max-pool ties go to the first element in (row, col) scan order; interpolation uses
 // align_corners=False, bicubic with A = -0.75 and border-clamped taps.
 #include "gmk_common.h"
+#include "plan.h"
 
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                            unsigned char* __restrict__ idx, long long planes, int H, int W) {
@@ -142,6 +143,7 @@ static inline int blocks_for(long long total) {
 }
 
 extern "C" int gmk_maxpool2_fwd(const float* x, float* y, unsigned char* idx, int64_t planes, int H, int W, gmk_stream_t stream) {
+  GMK_PLAN_HOOK(gmk_maxpool2_fwd, x, y, idx, planes, H, W, stream);
   GMK_REQUIRE(x && y, GMK_E_NULL);
   GMK_REQUIRE(planes > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, GMK_E_SHAPE);
   hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(blocks_for(planes * (H / 2) * (W / 2))), dim3(256), 0, (hipStream_t)stream, x, y, idx, (long long)planes, H, W);
@@ -149,6 +151,7 @@ extern "C" int gmk_maxpool2_fwd(const float* x, float* y, unsigned char* idx, in
   return GMK_OK;
 }
 extern "C" int gmk_maxpool2_bwd(const float* dy, const unsigned char* idx, const float* dact_in, float* dx, int64_t planes, int H, int W, gmk_stream_t stream) {
+  GMK_PLAN_HOOK(gmk_maxpool2_bwd, dy, idx, dact_in, dx, planes, H, W, stream);
   GMK_REQUIRE(dy && idx && dx, GMK_E_NULL);
   GMK_REQUIRE(planes > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, GMK_E_SHAPE);
   hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(blocks_for(planes * (H / 2) * (W / 2))), dim3(256), 0, (hipStream_t)stream, dy, idx, dact_in, dx, (long long)planes, H, W);
@@ -156,6 +159,7 @@ extern "C" int gmk_maxpool2_bwd(const float* dy, const unsigned char* idx, const
   return GMK_OK;
 }
 extern "C" int gmk_upsample2_fwd(const float* x, float* y, int64_t planes, int H, int W, int mode, gmk_stream_t stream) {
+  GMK_PLAN_HOOK(gmk_upsample2_fwd, x, y, planes, H, W, mode, stream);
   GMK_REQUIRE(x && y, GMK_E_NULL);
   GMK_REQUIRE(planes > 0 && H >= 1 && W >= 1, GMK_E_SHAPE);
   GMK_REQUIRE(mode >= GMK_UP_NEAREST && mode <= GMK_UP_BICUBIC, GMK_E_UNSUPPORTED);
@@ -164,6 +168,7 @@ extern "C" int gmk_upsample2_fwd(const float* x, float* y, int64_t planes, int H
   return GMK_OK;
 }
 extern "C" int gmk_upsample2_bwd(const float* dy, const float* dact_in, float* dx, int64_t planes, int H, int W, int mode, gmk_stream_t stream) {
+  GMK_PLAN_HOOK(gmk_upsample2_bwd, dy, dact_in, dx, planes, H, W, mode, stream);
   GMK_REQUIRE(dy && dx, GMK_E_NULL);
   GMK_REQUIRE(planes > 0 && H >= 1 && W >= 1, GMK_E_SHAPE);
   GMK_REQUIRE(mode >= GMK_UP_NEAREST && mode <= GMK_UP_BICUBIC, GMK_E_UNSUPPORTED);
@@ -172,6 +177,7 @@ extern "C" int gmk_upsample2_bwd(const float* dy, const float* dact_in, float* d
   return GMK_OK;
 }
 extern "C" int gmk_ew_mul(const float* a, const float* b, float* out, int64_t n, gmk_stream_t stream) {
+  GMK_PLAN_HOOK(gmk_ew_mul, a, b, out, n, stream);
   GMK_REQUIRE(a && b && out, GMK_E_NULL);
   GMK_REQUIRE(n > 0, GMK_E_SHAPE);
   hipLaunchKernelGGL(ew_mul_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long long)n);

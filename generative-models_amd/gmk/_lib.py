@@ -21,6 +21,13 @@ SIGNATURES = {
     "gmk_version": (_I, []),
     "gmk_stream_wait_stream": (_I, [_P, _P]),
     "gmk_strerror": (C.c_char_p, [_I]),
+    "gmk_plan_begin": (_I, [_P]),
+    "gmk_plan_mark": (_I, []),
+    "gmk_plan_end": (_I, []),
+    "gmk_plan_segments": (_I, [_P]),
+    "gmk_plan_calls": (_I, [_P]),
+    "gmk_plan_destroy": (None, [_P]),
+    "gmk_train_step_enqueue": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "gmk_conv_set_thin_paths": (_I, [_I, _I]),
     "gmk_conv_get_thin_paths": (_I, [_P, _P]),
     "gmk_conv2d_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -1,4 +1,4 @@
-"""Tensor-level wrappers over the C ABI (no autograd here; see gmk/functional.py).
+"""Tensor-level wrappers over the C ABI (no autograd here: the autograd.Functions live in models/autoencoders.py).
 
 Every function takes contiguous fp32 CUDA tensors, allocates its outputs with torch (device
 memory plumbing), and launches on torch's current stream.
@@ -9,6 +9,7 @@ import torch
 from ._lib import lib, check, act_id, UPSAMPLE_IDS
 
 _ws_cache = {}
+_ws_retired = []
 
 
 # Stream handle override: torch.cuda.current_stream() costs ~7 us of host time per call and every op asks for it; at ~80
@@ -42,6 +43,25 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+# While a launch plan is being recorded (gmk/plan.py) every tensor these wrappers allocate is appended to the plan's keep
+# list: the recorded pointers must stay valid, and owned by nobody else, for as long as the plan is replayed.
+_rec_keep = None
+
+
+def _new(shape, device, dtype=torch.float32):
+    t = torch.empty(shape, device=device, dtype=dtype)
+    if _rec_keep is not None:
+        _rec_keep.append(t)
+    return t
+
+
+def _new_like(x):
+    t = torch.empty_like(x)
+    if _rec_keep is not None:
+        _rec_keep.append(t)
+    return t
+
+
 def _chk(*ts):
     for t in ts:
         if t is None:
@@ -56,7 +76,15 @@ def workspace(nbytes, device):
     key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        # A workspace that has to grow is RETIRED, not freed: under a side-stream handle (SideQueue.run swaps the handle,
+        # not torch's current stream) the tensor belongs to the main stream's allocator pool, so dropping it would hand its
+        # memory to the next main-stream torch.empty while an earlier weight-gradient kernel on the side stream may still
+        # be using it as slab scratch; recorded launch plans also name it.  Growth is geometric, so the retired buffers
+        # of a key sum to less than the live one.
+        if ws is not None:
+            _ws_retired.append(ws)
+        grow = 0 if ws is None else 2 * ws.numel()
+        ws = torch.empty(max(int(nbytes), grow, 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
     return ws
 
@@ -74,6 +102,11 @@ class SideQueue:
         # runs; priority 0: never): a high-priority queue waiting on an event of a queue that is not scheduled.  A DP
         # job also runs more queues than the 4 hardware queues of a process (RCCL's), so the default stays 0.
         prio = int(os.environ.get("GMK_SIDE_PRIORITY", "0"))
+        if prio != 0 and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise RuntimeError("GMK_SIDE_PRIORITY != 0 is refused in a multi-process job: high-priority weight-gradient "
+                               "streams hung 3 of 3 two-rank runs (a high-priority queue waiting on an event of a queue "
+                               "that is not scheduled; a DP rank runs main + 2 side + RCCL streams on the 4 hardware "
+                               "queues of a process).  Unset it, or run single-process.")
         # GMK_SIDE_STREAMS=n: the weight-gradient launches alternate over n side streams.  Default 2: 1.056 -> 1.021 ms per step
         # once the host stopped bounding the step (1 -> 2 -> 3 -> 4 streams: 1.056 / 1.021 / 1.021 / 1.040 ms; while the step was
         # host-bound, round 2 first measured two streams 1-3 % slower)
@@ -165,8 +198,8 @@ def conv2d_fwd(x, w, bias, stride=1, act=None, want_dact=False):
     _chk(x, w, bias)
     N, Cin, H, W = x.shape
     Cout, _, k, _ = w.shape
-    y = torch.empty((N, Cout, H // stride, W // stride), device=x.device, dtype=torch.float32)
-    dact = torch.empty_like(y) if want_dact else None
+    y = _new((N, Cout, H // stride, W // stride), x.device, torch.float32)
+    dact = _new_like(y) if want_dact else None
     check(lib().gmk_conv2d_fwd(_p(x), _p(w), _p(bias), _p(y), _p(dact), N, Cin, H, W, Cout, k, stride, act_id(act), _stream()))
     return (y, dact) if want_dact else y
 
@@ -175,7 +208,7 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, dact_in=None):
     _chk(dy, w, dact_in)
     N, Cin, H, W = x_shape
     Cout, _, k, _ = w.shape
-    dx = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
+    dx = _new(x_shape, dy.device, torch.float32)
     check(lib().gmk_conv2d_dgrad(_p(dy), _p(w), _p(dact_in), _p(dx), N, Cin, H, W, Cout, k, stride, _stream()))
     return dx
 
@@ -189,8 +222,8 @@ def conv2d_wgrad(dy, x, ksize, stride=1, want_bias=True, out=None):
         dw, db = out
         _chk(dw, db)
     else:
-        dw = torch.empty((Cout, Cin, ksize, ksize), device=x.device, dtype=torch.float32)
-        db = torch.empty((Cout,), device=x.device, dtype=torch.float32) if want_bias else None
+        dw = _new((Cout, Cin, ksize, ksize), x.device, torch.float32)
+        db = _new((Cout,), x.device, torch.float32) if want_bias else None
     nb = lib().gmk_conv2d_wgrad_workspace_bytes(N, Cin, H, W, Cout, ksize, stride)
     ws = workspace(nb, x.device)
     check(lib().gmk_conv2d_wgrad(_p(dy), _p(x), _p(dw), _p(db), N, Cin, H, W, Cout, ksize, stride, _p(ws), ws.numel(), _stream()))
@@ -201,8 +234,8 @@ def deconv2d_fwd(x, w, bias, act=None, want_dact=False):
     _chk(x, w, bias)
     N, Cin, H, W = x.shape
     _, Cout, k, _ = w.shape
-    y = torch.empty((N, Cout, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
-    dact = torch.empty_like(y) if want_dact else None
+    y = _new((N, Cout, 2 * H, 2 * W), x.device, torch.float32)
+    dact = _new_like(y) if want_dact else None
     check(lib().gmk_deconv2d_fwd(_p(x), _p(w), _p(bias), _p(y), _p(dact), N, Cin, H, W, Cout, k, act_id(act), _stream()))
     return (y, dact) if want_dact else y
 
@@ -211,7 +244,7 @@ def deconv2d_dgrad(dy, w, x_shape, dact_in=None):
     _chk(dy, w, dact_in)
     N, Cin, H, W = x_shape
     _, Cout, k, _ = w.shape
-    dx = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
+    dx = _new(x_shape, dy.device, torch.float32)
     check(lib().gmk_deconv2d_dgrad(_p(dy), _p(w), _p(dact_in), _p(dx), N, Cin, H, W, Cout, k, _stream()))
     return dx
 
@@ -224,8 +257,8 @@ def deconv2d_wgrad(dy, x, ksize, want_bias=True, out=None):
         dw, db = out
         _chk(dw, db)
     else:
-        dw = torch.empty((Cin, Cout, ksize, ksize), device=x.device, dtype=torch.float32)
-        db = torch.empty((Cout,), device=x.device, dtype=torch.float32) if want_bias else None
+        dw = _new((Cin, Cout, ksize, ksize), x.device, torch.float32)
+        db = _new((Cout,), x.device, torch.float32) if want_bias else None
     nb = lib().gmk_deconv2d_wgrad_workspace_bytes(N, Cin, H, W, Cout, ksize)
     ws = workspace(nb, x.device)
     check(lib().gmk_deconv2d_wgrad(_p(dy), _p(x), _p(dw), _p(db), N, Cin, H, W, Cout, ksize, _p(ws), ws.numel(), _stream()))
@@ -236,8 +269,8 @@ def linear_fwd(x, w, bias, act=None, want_dact=False):
     _chk(x, w, bias)
     M, K = x.shape
     N = w.shape[0]
-    y = torch.empty((M, N), device=x.device, dtype=torch.float32)
-    dact = torch.empty_like(y) if want_dact else None
+    y = _new((M, N), x.device, torch.float32)
+    dact = _new_like(y) if want_dact else None
     ws = workspace(lib().gmk_linear_workspace_bytes(M, K, N), x.device)
     check(lib().gmk_linear_fwd(_p(x), _p(w), _p(bias), _p(y), _p(dact), M, K, N, act_id(act), _p(ws), ws.numel(), _stream()))
     return (y, dact) if want_dact else y
@@ -247,7 +280,7 @@ def linear_dgrad(dy, w, dact_in=None):
     _chk(dy, w, dact_in)
     M, N = dy.shape
     K = w.shape[1]
-    dx = torch.empty((M, K), device=dy.device, dtype=torch.float32)
+    dx = _new((M, K), dy.device, torch.float32)
     ws = workspace(lib().gmk_linear_workspace_bytes(M, K, N), dy.device)
     check(lib().gmk_linear_dgrad(_p(dy), _p(w), _p(dact_in), _p(dx), M, K, N, _p(ws), ws.numel(), _stream()))
     return dx
@@ -261,8 +294,8 @@ def linear_wgrad(dy, x, want_bias=True, out=None):
         dw, db = out
         _chk(dw, db)
     else:
-        dw = torch.empty((N, K), device=x.device, dtype=torch.float32)
-        db = torch.empty((N,), device=x.device, dtype=torch.float32) if want_bias else None
+        dw = _new((N, K), x.device, torch.float32)
+        db = _new((N,), x.device, torch.float32) if want_bias else None
     ws = workspace(lib().gmk_linear_workspace_bytes(M, K, N), x.device)
     check(lib().gmk_linear_wgrad(_p(dy), _p(x), _p(dw), _p(db), M, K, N, _p(ws), ws.numel(), _stream()))
     return dw, db
@@ -273,8 +306,8 @@ def linear_fwd_reparam(x, w, bias, eps):
     _chk(x, w, bias, eps)
     M, K = x.shape
     N = w.shape[0]
-    stats = torch.empty((M, N // 2, 2), device=x.device, dtype=torch.float32)
-    z = torch.empty((M, N // 2), device=x.device, dtype=torch.float32)
+    stats = _new((M, N // 2, 2), x.device, torch.float32)
+    z = _new((M, N // 2), x.device, torch.float32)
     ws = workspace(lib().gmk_linear_workspace_bytes(M, K, N), x.device)
     check(lib().gmk_linear_fwd_reparam(_p(x), _p(w), _p(bias), _p(eps), _p(stats), _p(z), M, K, N, _p(ws), ws.numel(), _stream()))
     return stats, z
@@ -285,7 +318,7 @@ def linear_dgrad_reparam(dy, w, stats, eps, kl_scale, mse_prior=False):
     _chk(dy, w, stats, eps)
     M, N = dy.shape
     K = w.shape[1]
-    dstats = torch.empty_like(stats)
+    dstats = _new_like(stats)
     ws = workspace(lib().gmk_linear_workspace_bytes(M, K, N), dy.device)
     check(lib().gmk_linear_dgrad_reparam(_p(dy), _p(w), _p(stats), _p(eps), _p(dstats), M, K, N, float(kl_scale),
                                          1 if mse_prior else 0, _p(ws), ws.numel(), _stream()))
@@ -295,7 +328,7 @@ def linear_dgrad_reparam(dy, w, stats, eps, kl_scale, mse_prior=False):
 def reparam_fwd(stats, eps):
     _chk(stats, eps)
     B, L, _ = stats.shape
-    z = torch.empty((B, L), device=stats.device, dtype=torch.float32)
+    z = _new((B, L), stats.device, torch.float32)
     check(lib().gmk_reparam_fwd(_p(stats), _p(eps), _p(z), B, L, _stream()))
     return z
 
@@ -305,7 +338,7 @@ def reparam_bwd(dz, stats, eps, dstats=None):
     B, L, _ = stats.shape
     acc = 1
     if dstats is None:
-        dstats = torch.empty_like(stats)
+        dstats = _new_like(stats)
         acc = 0
     check(lib().gmk_reparam_bwd(_p(dz), _p(stats), _p(eps), _p(dstats), B, L, acc, _stream()))
     return dstats
@@ -318,10 +351,18 @@ _loss_sync = {}
 
 
 def _loss_state(device):
-    """Per-device private (partials workspace, zeroed 256-byte sync word block) of the one-launch loss kernel: unlike the
-    shared byte workspace these must not be touched by any other op (the kernel keeps the sync block at zero)."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    """Private (partials workspace, zeroed 256-byte sync word block) of the one-launch loss kernel per (device, stream):
+    unlike the shared byte workspace these must not be touched by any other op (the kernel keeps the sync block at zero),
+    and two streams must not share them (their launches could overlap and split one ticket count)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
     st = _loss_sync.get(key)
+    if st is None and torch.cuda.is_current_stream_capturing():
+        # nothing may be created (zero fill + synchronize) under HIP graph capture: take the state a warm-up step made
+        # on this device (the captured step is the only user of it while the graph replays: its streams are graph edges)
+        st = next((v for k, v in _loss_sync.items() if k[0] == key[0]), None)
+        if st is None:
+            raise RuntimeError("run one eager train step on this device before capturing it into a graph")
+        return st
     if st is None:
         ws = torch.empty(int(lib().gmk_vae_loss_workspace_bytes()), dtype=torch.uint8, device=device)
         sync = torch.zeros(256, dtype=torch.uint8, device=device)
@@ -337,10 +378,10 @@ def vae_loss_fwd_bwd(pre, image, stats, beta, sigmoid=True, mse_prior=False, wan
     B = pre.shape[0]
     chw = pre.numel() // B
     L = 0 if stats is None else stats.shape[1]
-    dpre = torch.empty_like(pre)
-    dstats = None if (stats is None or not want_dstats) else torch.empty_like(stats)
-    recon = torch.empty_like(pre) if want_recon else None
-    losses = torch.empty(3, device=pre.device, dtype=torch.float32)
+    dpre = _new_like(pre)
+    dstats = None if (stats is None or not want_dstats) else _new_like(stats)
+    recon = _new_like(pre) if want_recon else None
+    losses = _new(3, pre.device, torch.float32)
     ws = workspace(lib().gmk_vae_loss_workspace_bytes(), pre.device)
     flags = (LOSS_SIGMOID if sigmoid else 0) | (LOSS_MSE_PRIOR if mse_prior else 0) | (0 if want_dstats else LOSS_NO_DSTATS)
     if fused:   # one launch (the last block finalizes); private workspace + sync block, main-stream callers only
@@ -359,8 +400,8 @@ def vae_loss_eval(pre, image, stats, beta, sigmoid=True, mse_prior=False, want_r
     B = pre.shape[0]
     chw = pre.numel() // B
     L = 0 if stats is None else stats.shape[1]
-    recon = torch.empty_like(pre) if want_recon else None
-    out5 = torch.empty(5, device=pre.device, dtype=torch.float32)
+    recon = _new_like(pre) if want_recon else None
+    out5 = _new(5, pre.device, torch.float32)
     ws = workspace(lib().gmk_vae_loss_workspace_bytes(), pre.device)
     flags = (LOSS_SIGMOID if sigmoid else 0) | (LOSS_MSE_PRIOR if mse_prior else 0)
     check(lib().gmk_vae_loss_eval(_p(pre), _p(image), _p(stats), _p(recon), _p(out5), B, chw, L, float(beta), flags,
@@ -371,8 +412,8 @@ def vae_loss_eval(pre, image, stats, beta, sigmoid=True, mse_prior=False, want_r
 def maxpool2_fwd(x, want_idx=True):
     _chk(x)
     N, C, H, W = x.shape
-    y = torch.empty((N, C, H // 2, W // 2), device=x.device, dtype=torch.float32)
-    idx = torch.empty((N, C, H // 2, W // 2), device=x.device, dtype=torch.uint8) if want_idx else None
+    y = _new((N, C, H // 2, W // 2), x.device, torch.float32)
+    idx = _new((N, C, H // 2, W // 2), x.device, torch.uint8) if want_idx else None
     check(lib().gmk_maxpool2_fwd(_p(x), _p(y), _p(idx), N * C, H, W, _stream()))
     return (y, idx) if want_idx else y
 
@@ -380,7 +421,7 @@ def maxpool2_fwd(x, want_idx=True):
 def maxpool2_bwd(dy, idx, dact_in=None):
     _chk(dy, dact_in)
     N, C, OH, OW = dy.shape
-    dx = torch.empty((N, C, 2 * OH, 2 * OW), device=dy.device, dtype=torch.float32)
+    dx = _new((N, C, 2 * OH, 2 * OW), dy.device, torch.float32)
     check(lib().gmk_maxpool2_bwd(_p(dy), _p(idx), _p(dact_in), _p(dx), N * C, 2 * OH, 2 * OW, _stream()))
     return dx
 
@@ -390,7 +431,7 @@ def upsample2_fwd(x, mode="nearest"):
     if mode not in UPSAMPLE_IDS:
         raise NotImplementedError(f"interpolation mode {mode!r} is not valid for 4-D input (nearest|bilinear|bicubic)")
     N, C, H, W = x.shape
-    y = torch.empty((N, C, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+    y = _new((N, C, 2 * H, 2 * W), x.device, torch.float32)
     check(lib().gmk_upsample2_fwd(_p(x), _p(y), N * C, H, W, UPSAMPLE_IDS[mode], _stream()))
     return y
 
@@ -398,14 +439,14 @@ def upsample2_fwd(x, mode="nearest"):
 def upsample2_bwd(dy, mode="nearest", dact_in=None):
     _chk(dy, dact_in)
     N, C, OH, OW = dy.shape
-    dx = torch.empty((N, C, OH // 2, OW // 2), device=dy.device, dtype=torch.float32)
+    dx = _new((N, C, OH // 2, OW // 2), dy.device, torch.float32)
     check(lib().gmk_upsample2_bwd(_p(dy), _p(dact_in), _p(dx), N * C, OH // 2, OW // 2, UPSAMPLE_IDS[mode], _stream()))
     return dx
 
 
 def ew_mul(a, b):
     _chk(a, b)
-    out = torch.empty_like(a)
+    out = _new_like(a)
     check(lib().gmk_ew_mul(_p(a), _p(b), _p(out), a.numel(), _stream()))
     return out
 

@@ -314,8 +314,74 @@ class Autoencoder(nn.Module):
         backward pass -- nothing later in backward reads those weights.  The caller still calls optimizer.step() after
         train_step, as main.py:52 does: it updates the rest and advances the step count (FusedAdamW.step_range).
         Bit-identical to the plain order; measured at B = 256 on one GPU it hides 15 us of GPU time and costs 120 us of
-        host time in a step whose host time (0.85 ms) is close to its GPU time (1.05 ms), so nothing passes it by default.
+        host time, so nothing passes it by default.
+
+        Launch plan (gmk/plan.py; GMK_STEP_PLAN=0 turns it off): the first step with a given (batch shape, beta, parameter
+        storage, stream) runs through the Python path below while libgmk records its ~85 entry-point calls; every later
+        step with the same key is ONE C call per gradient bucket that re-issues them with the new image / eps pointers
+        (gmk_train_step_enqueue): bit-identical results, 0.8 -> ~0.2 ms of host time per step.  A replayed step returns
+        the SAME tensors every step (losses, .stats, .latent_vector are overwritten in stream order): read or copy what
+        you want to keep before the next step.  One plan is cached per model (a new key re-records).
         """
+        early = optimizer is not None and hasattr(optimizer, "step_range")
+        if early or os.environ.get("GMK_STEP_PLAN", "1") == "0" or torch.cuda.is_current_stream_capturing():
+            return self._train_step_py(image, beta, mse_prior, eps, reducer, optimizer)
+        from gmk.plan import StepPlan
+        image = image.contiguous()
+        B = image.shape[0]
+        if self.variational:
+            if eps is None:
+                eps = torch.randn((B, self.latent_size), device=image.device, dtype=torch.float32)
+            eps = eps.contiguous()
+        else:
+            eps = None
+        main_stream = torch.cuda.current_stream(image.device)
+        self._step_tensors()
+        dp = reducer is not None and reducer.world > 1
+        key = (tuple(image.shape), float(beta), bool(mse_prior), main_stream.cuda_stream, dp, self._step_cache[3],
+               bool(self.decoder.use_sigmoid), self.encoder._act_id, self.decoder._interp, os.environ.get("GMK_SIDE_WGRAD", "1"))
+        cached = getattr(self, "_step_plan", None)
+        if cached is None or cached[0] != key:
+            if cached is not None:      # frees the old plan's activations before the new recording allocates its own
+                cached[1].close()
+                self._step_plan = None
+            plan = StepPlan()
+            with plan:
+                plan.out = self._train_step_py(image, beta, mse_prior, eps, reducer, optimizer, rec=plan)
+            plan.set_inputs(image, eps)
+            plan.stats, plan.z = (self.stats if self.variational else None), self.latent_vector
+            self._step_plan = (key, plan)
+            return plan.out
+        plan = cached[1]
+        if dp:
+            side = ops.side_queue(image.device)
+            a = 0
+            for name, seg in plan.marks:
+                plan.enqueue(a, seg + 1, image, eps)
+                a = seg + 1
+                self._bucket_ready(name, reducer, side)
+            plan.enqueue(a, plan.nseg, image, eps)
+        else:
+            plan.enqueue(0, plan.nseg, image, eps)
+        if self.variational:
+            self.stats, self.normal = plan.stats, eps
+        self.latent_vector = plan.z
+        return plan.out
+
+    @staticmethod
+    def _bucket_ready(name, reducer, side):
+        """Gradient bucket `name` is enqueued: start its all-reduce behind the weight-gradient streams."""
+        if reducer is None or reducer.world == 1:
+            return
+        if side is None:
+            reducer.ready(name)
+        else:  # the bucket's gradients are ordered on the side stream(s): the all-reduce waits for them
+            side.gather()
+            with torch.cuda.stream(side.stream):
+                reducer.ready(name)
+
+    def _train_step_py(self, image, beta=0.0, mse_prior=False, eps=None, reducer=None, optimizer=None, rec=None):
+        """The step launch by launch from Python (and the recording pass of a launch plan: `rec`)."""
         # one stream lookup per step: every gmk op below takes the handle from the scope (gmk.ops.stream_scope)
         main_stream = torch.cuda.current_stream(image.device)
         with ops.stream_scope(main_stream):
@@ -355,13 +421,9 @@ class Autoencoder(nn.Module):
                 opt_stream = ops.aux_stream(image.device)
 
             def bucket_ready(name):
-                if reducer is not None:
-                    if side is None:
-                        reducer.ready(name)
-                    else:  # the bucket's gradients are ordered on the side stream(s): the all-reduce waits for them
-                        side.gather()
-                        with torch.cuda.stream(side.stream):
-                            reducer.ready(name)
+                if rec is not None:
+                    rec.mark(name)
+                self._bucket_ready(name, reducer, side)
                 if early and name != "encoder.conv":
                     # the update must follow the bucket's weight gradients (side stream), the kernels that read its weights
                     # (main stream, all enqueued by now) and its all-reduce

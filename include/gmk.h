@@ -10,8 +10,12 @@
  *     the caller; the library never allocates, frees or retains a pointer;
  *   - tensors are fp32, contiguous, NCHW (activations), OIHW (conv weights), IOHW (transposed-conv
  *     weights), [out][in] (linear weights): the layouts of the reference's state_dict;
- *   - asynchronous launch on `stream` (a hipStream_t passed as void*; NULL = default stream),
- *     no internal synchronisation, no global mutable state;
+ *   - asynchronous launch on `stream` (a hipStream_t passed as void*; NULL = default stream), no internal
+ *     synchronisation, re-entrant across streams and devices.  State the library keeps, all of it listed here: (1) the
+ *     per-device kernel-path selection of gmk_conv_set_thin_paths (one atomic word per device); (2) per-device caches that
+ *     only ever grow (event ring of gmk_stream_wait_stream, raised dynamic-LDS limits, the address of the static scratch of
+ *     gmk_vae_loss_fwd_bwd_static); (3) the calling thread's plan being recorded between gmk_plan_begin / gmk_plan_end;
+ *     (4) profiling knobs read once from the environment (GMK_WINO, GMK_*_DBG: ablation builds, 0 in production);
  *   - return 0 on success, a negative GMK_E_* on a rejected argument, a positive hipError_t if a
  *     launch failed; gmk_strerror() names either.
  *   - spatial sizes must be powers of two (the reference fixes 32x32; 64x64 for config 5).
@@ -34,7 +38,8 @@ enum gmk_error {
   GMK_E_UNSUPPORTED = -3, /* unsupported option (kernel size, activation, mode) */
   GMK_E_WORKSPACE = -4,   /* workspace too small */
   GMK_E_NULL = -5,        /* required pointer is NULL */
-  GMK_E_TOO_LARGE = -6    /* input exceeds the stated maximum of an allocation-free (static scratch) entry point */
+  GMK_E_TOO_LARGE = -6,   /* input exceeds the stated maximum of an allocation-free (static scratch) entry point */
+  GMK_E_STATE = -7        /* call out of order: gmk_plan_begin while recording, gmk_plan_mark / _end while not, replay of a plan still being recorded */
 };
 
 /* /root/reference/utils.py:49-66 get_activation_function */
@@ -52,7 +57,8 @@ enum gmk_act {
 
 int gmk_version(void);
 /* gmk_stream_wait_stream: everything enqueued on `waiter` after this call runs behind everything enqueued on `on`
- *   before it (hipEventRecord + hipStreamWaitEvent on an event of a per-device ring of 64, created on first use).
+ *   before it (hipEventRecord + hipStreamWaitEvent on an event of a ring of 64 per device, created on first use; the ring
+ *   is that of the device that owns `on`, whatever the current device).
  *   No counterpart in the reference: host plumbing of the backward pass's second stream (weight gradients), which
  *   autograd's single stream does not have (main.py:51). */
 int gmk_stream_wait_stream(gmk_stream_t waiter, gmk_stream_t on);
@@ -62,11 +68,39 @@ const char* gmk_strerror(int code);
  *   the image side.  thin_in: bit 0 = forward of a Cin <= 4 layer, bit 1 = data gradient of a Cout <= 4 layer on
  *   conv_thin_in.hip (else the implicit GEMM); thin_outv: 1 = forward of a Cout <= 4 layer on conv_thin_outv.hip (else
  *   conv_thin_out.hip).  A negative argument leaves that setting as it is.  Defaults: 3 and 1, or the GMK_THIN_IN /
- *   GMK_THIN_OUTV environment variables.  Process-wide; call it between launches, not concurrently with them.
- *   No counterpart in the reference: the faster choice differs between devices of the same model (DESIGN.md section 7),
+ *   GMK_THIN_OUTV environment variables.  PER DEVICE: both calls act on the calling thread's current device, and a launch
+ *   reads the word of its thread's current device (atomic: a concurrent setter yields one of the two valid choices).
+ *   No counterpart in the reference: the faster choice differs between devices of the same model (DESIGN.md section 5),
  *   so a host may time its step both ways once and keep the better one (gmk/tune.py). */
 int gmk_conv_set_thin_paths(int thin_in, int thin_outv);
 int gmk_conv_get_thin_paths(int* thin_in, int* thin_outv);
+
+/* ---------------------------------------------------------------- launch plans ----------
+ * The train step of /root/reference/main.py:27-53 is ~60 kernel launches and ~25 stream fork/join edges; issued one by
+ * one from Python + ctypes they cost 0.8 ms of host time against 1.0 ms of GPU time at batch 256.  A plan records them
+ * once and replays them from C:
+ * gmk_plan_begin(&plan): from now until gmk_plan_end(), every launching entry point of this header called on THIS host
+ *   thread (conv / deconv / linear / loss / reparam / pool / upsample / ew_mul / gmk_stream_wait_stream) runs as usual and
+ *   is also appended to the plan: its own address and its arguments by value.  One recording per thread at a time.
+ * gmk_plan_mark(): closes the current segment and returns its index (>= 0): the host side marks the points where it has
+ *   work of its own between launches (a gradient bucket's all-reduce).  gmk_plan_end() closes the last segment.
+ * gmk_train_step_enqueue(plan, seg_begin, seg_end, nsub, from, to, bytes): calls the recorded entry points of segments
+ *   [seg_begin, seg_end) again, in order, on the recorded streams, with the recorded arguments -- except that a pointer
+ *   argument inside [from[i], from[i] + bytes[i]) is moved to to[i] + (p - from[i]): that is how a step gets its new image
+ *   batch and noise.  Same entry points, so same argument checks, kernel selection and results as direct calls (bit for bit).
+ *   Returns the first non-zero return code, 0 otherwise.
+ *   The CALLER keeps every buffer named in the plan alive and in place for as long as the plan is replayed (outputs and
+ *   workspaces of the recorded step become the outputs of every replay), keeps the streams alive, and replays on the
+ *   device that recorded.  The plan holds no device memory.  gmk_plan_destroy frees the host-side list. */
+typedef struct gmk_plan gmk_plan;
+int gmk_plan_begin(gmk_plan** plan);
+int gmk_plan_mark(void);
+int gmk_plan_end(void);
+int gmk_plan_segments(const gmk_plan* plan);
+int gmk_plan_calls(const gmk_plan* plan);
+void gmk_plan_destroy(gmk_plan* plan);
+int gmk_train_step_enqueue(const gmk_plan* plan, int seg_begin, int seg_end, int nsub, const void* const* from,
+                           const void* const* to, const size_t* bytes);
 
 /* ---------------------------------------------------------------- convolutions ----------
  * Implicit-GEMM fp32-MFMA kernels (v_mfma_f32_32x32x2_f32), LDS-staged input patch + weights.

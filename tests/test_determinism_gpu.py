@@ -71,3 +71,65 @@ def test_train_step_captures_into_a_hip_graph_and_replays_exactly():
     torch.cuda.synchronize()
     assert torch.equal(g_losses, e_losses)
     assert torch.equal(opt.flat_grad, ref)
+
+
+def _vae(dev, seed=0):
+    from models.autoencoders import Autoencoder
+    from utils import get_activation_function
+    from gmk.optim import FusedAdamW
+    torch.manual_seed(seed)
+    m = Autoencoder(variational=True, latent_size=256, num_channels=64, kernel_size=3, act=get_activation_function("gelu"),
+                    sigmoid=True, interpolation="nearest", no_pool=True, no_upsample=True, device=dev).to(dev)
+    return m, FusedAdamW(m.parameters(), lr=1e-3, weight_decay=0.01)
+
+
+def test_launch_plan_replay_is_bit_identical_to_the_python_path(monkeypatch):
+    """gmk_train_step_enqueue (one C call re-issuing the recorded entry-point calls with substituted image / eps pointers)
+    against the launch-by-launch Python path: same gradients, losses, stats and z, bit for bit, on every step -- the
+    recording step, replays on new inputs in NEW buffers, a beta change (re-record) and a batch-size change."""
+    dev = torch.device("cuda:0")
+    ma, oa = _vae(dev)
+    mb, ob = _vae(dev)
+    g = torch.Generator(device=dev).manual_seed(11)
+    sched = [(256, 5e-6)] * 4 + [(256, 5.1e-6)] * 2 + [(64, 5.1e-6)] * 2
+    for i, (B, beta) in enumerate(sched):
+        x = torch.rand(B, 3, 32, 32, device=dev, generator=g)
+        eps = torch.randn(B, 256, device=dev, generator=g)
+        monkeypatch.setenv("GMK_STEP_PLAN", "0")
+        la = ma.train_step(x, beta=beta, eps=eps).clone()
+        monkeypatch.setenv("GMK_STEP_PLAN", "1")
+        lb = mb.train_step(x.clone(), beta=beta, eps=eps.clone()).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(la, lb), (i, la, lb)
+        assert torch.equal(oa.flat_grad, ob.flat_grad), (i, float((oa.flat_grad - ob.flat_grad).abs().max()))
+        assert torch.equal(ma.stats, mb.stats) and torch.equal(ma.latent_vector, mb.latent_vector)
+        oa.step(); ob.step()
+        assert torch.equal(oa.flat_param, ob.flat_param)
+    key, plan = mb._step_plan
+    from gmk import lib
+    assert lib().gmk_plan_calls(plan.handle) >= 40 and plan.nseg == 4   # ~26 entry-point calls + the fork/join edges
+
+
+def test_first_step_from_cold_workspaces_matches_the_single_stream_step(monkeypatch):
+    """Round-2 advisor finding: a side-stream workspace that has to GROW (first step, layers of increasing slab size)
+    was dropped into the main stream's allocator pool while a weight-gradient kernel could still be using it.  Grown
+    workspaces are now retired, not freed: step 1 from an empty workspace cache, with main-stream allocations right
+    behind every launch, must give the single-stream step's gradients bit for bit."""
+    from gmk import ops
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("GMK_STEP_PLAN", "0")
+    g = torch.Generator(device=dev).manual_seed(13)
+    x = torch.rand(256, 3, 32, 32, device=dev, generator=g)
+    eps = torch.randn(256, 256, device=dev, generator=g)
+    monkeypatch.setenv("GMK_SIDE_WGRAD", "0")
+    m0, o0 = _vae(dev)
+    m0.train_step(x, beta=5e-6, eps=eps)
+    torch.cuda.synchronize()
+    ref = o0.flat_grad.clone()
+    monkeypatch.setenv("GMK_SIDE_WGRAD", "1")
+    ops._ws_cache.clear()
+    torch.cuda.empty_cache()
+    m1, o1 = _vae(dev)
+    m1.train_step(x, beta=5e-6, eps=eps)
+    torch.cuda.synchronize()
+    assert torch.equal(o1.flat_grad, ref), float((o1.flat_grad - ref).abs().max())

@@ -143,6 +143,39 @@ def test_library_exports_every_declared_symbol():
     assert handle.gmk_strerror(-4).decode().startswith("gmk:")
 
 
+def test_launch_plan_api_state_machine_without_a_gpu():
+    """gmk_plan_* bookkeeping (host-only code): order errors are GMK_E_STATE, an empty plan replays as a no-op."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "generative-models_amd"))
+    import gmk
+    h = gmk.lib()
+    E_STATE, E_SHAPE = -7, -1
+    assert h.gmk_plan_mark() == E_STATE and h.gmk_plan_end() == E_STATE
+    p = C.c_void_p()
+    assert h.gmk_plan_begin(C.byref(p)) == 0 and p.value
+    q = C.c_void_p()
+    assert h.gmk_plan_begin(C.byref(q)) == E_STATE
+    assert h.gmk_train_step_enqueue(p, 0, 0, 0, None, None, None) == E_STATE      # still recording
+    assert h.gmk_plan_mark() == 0 and h.gmk_plan_mark() == 1
+    assert h.gmk_plan_end() == 0
+    assert h.gmk_plan_segments(p) == 2 and h.gmk_plan_calls(p) == 0
+    assert h.gmk_train_step_enqueue(p, 0, 2, 0, None, None, None) == 0
+    assert h.gmk_train_step_enqueue(p, 1, 3, 0, None, None, None) == E_SHAPE
+    h.gmk_plan_destroy(p)
+    assert h.gmk_strerror(E_STATE).decode().startswith("gmk:")
+
+
+def test_side_priority_is_refused_in_multi_process_jobs(monkeypatch):
+    """High-priority weight-gradient streams hung two-rank runs in round 2: the knob is refused
+    when WORLD_SIZE > 1 instead of being a documented trap.  The check runs before any stream is created."""
+    sys.path.insert(0, os.path.join(ROOT, "generative-models_amd"))
+    from gmk import ops
+    monkeypatch.setenv("GMK_SIDE_PRIORITY", "-1")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(RuntimeError, match="GMK_SIDE_PRIORITY"):
+        ops.SideQueue(torch.device("cpu"))
+
+
 def test_fused_adamw_is_a_torch_adamw_with_reference_state_layout():
     sys.path.insert(0, os.path.join(ROOT, "generative-models_amd"))
     import torch.nn as nn

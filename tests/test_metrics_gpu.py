@@ -50,6 +50,31 @@ def test_moments_match_oracle_and_are_batching_invariant():
     assert np.allclose(outs[0][0], outs[2][0], rtol=1e-13, atol=1e-10)
 
 
+def test_gram_wide_features_on_the_unaligned_fallback_kernel():
+    """D = 512 through the 64-tile fallback kernel (X not 16-byte aligned): it uses up to 32 slabs where the 128-tile plan
+    has 25, so the workspace must be sized for the larger of the two plans (round-2 advisor finding: out-of-bounds slab
+    writes).  Checked against the aligned path (exact fp64 sums of exact products: equal to ~1e-12 relative) and numpy."""
+    from gmk import ops
+    n, D = 16384, 512
+    g = torch.Generator(device="cuda").manual_seed(3)
+    buf = torch.randn(n * D + 4, device="cuda", generator=g)
+    xa = buf[:n * D].view(n, D)
+    xu = buf[1:1 + n * D].view(n, D)          # 4-byte aligned only
+    assert xu.data_ptr() % 16 != 0 and xu.is_contiguous()
+    guard = torch.full((1 << 16,), 7.0, device="cuda", dtype=torch.float64)   # allocated next: a canary behind the workspace
+    res = []
+    for x in (xa, xu):
+        G = torch.zeros(D, D, dtype=torch.float64, device="cuda")
+        s = torch.zeros(D, dtype=torch.float64, device="cuda")
+        ops.gram_accumulate(x, G, s)
+        torch.cuda.synchronize()
+        ref = x.double().T @ x.double()
+        assert torch.allclose(G, ref, rtol=1e-11, atol=1e-9), float((G - ref).abs().max())
+        assert torch.allclose(s, x.double().sum(0), rtol=1e-11, atol=1e-9)
+        res.append(G)
+    assert bool((guard == 7.0).all())
+
+
 def test_fid_small_and_rank_deficient(metrics_golden):
     import metrics
     f1 = torch.from_numpy(_fid_features("fid/small1", 300, 16, 0.5, 1.0)).cuda()

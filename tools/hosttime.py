@@ -21,6 +21,7 @@ for n in (3, 3, 10):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print(f"n={n}: host enqueue {1e3*(t1-t0)/n:.3f} ms/step, total {1e3*(t2-t0)/n:.3f} ms/step")
+print("GMK_STEP_PLAN =", os.environ.get("GMK_STEP_PLAN", "1"))
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for _ in range(20): step()

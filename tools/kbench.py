@@ -54,10 +54,13 @@ def cases():
 
 
 def main():
-    pat = [a for a in sys.argv[1:] if not a.startswith("--")]
+    argv = sys.argv[1:]
     iters = 20
-    if "--iters" in sys.argv:
-        iters = int(sys.argv[sys.argv.index("--iters") + 1])
+    if "--iters" in argv:
+        k = argv.index("--iters")
+        iters = int(argv[k + 1])
+        del argv[k:k + 2]
+    pat = [a for a in argv if not a.startswith("--")]
     tot = 0.0
     for name, (fn, flops) in cases().items():
         if pat and not any(p in name for p in pat):
