@@ -43,67 +43,85 @@ def build(device):
     return model, optim, sched
 
 
-def _time_conv(device, stride, iters):
-    """HIP-event time per launch of the 64->64 3x3 conv forward (+GELU, +act') at B=256: 16x16 input for stride 1
-    (enc.conv2 / dec.conv2), 32x32 input for stride 2 (enc.downsample1), on the launch stream."""
-    from gmk import ops
-    N, C, H = PER_GPU_BATCH, 64, 16 * stride
-    x = torch.rand(N, C, H, H, device=device)
-    w = (torch.rand(C, C, 3, 3, device=device) - 0.5) * 0.1
-    b = torch.zeros(C, device=device)
+def _time_launches(fn, iters):
+    """HIP-event time per launch of fn() on the launch stream (torch's current stream = the stream the ops launch on)."""
     for _ in range(5):
-        ops.conv2d_fwd(x, w, b, stride=stride, act="gelu", want_dact=True)
+        fn()
     torch.cuda.synchronize()
     s = torch.cuda.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(s)
     for _ in range(iters):
-        ops.conv2d_fwd(x, w, b, stride=stride, act="gelu", want_dact=True)
+        fn()
     e1.record(s)
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def dominant_kernel_roofline(device, iters=30):
-    """The hot conv layer of the step (64->64 3x3 stride 1 at 16x16, B=256) timed alone.  `achieved` / `frac` are
-    ALGORITHMIC FLOPs (direct convolution: 2*Cout*Cin*9 per output pixel) over the launch time, as SURVEY 8(d)
-    defines them; since round 2 the layer runs as Winograd F(2x2,3x3) (conv_wino.hip), which executes 16/36 of those
-    multiplies on the matrix cores -- `mfma_flops_executed` / `mfma_frac_executed` state that separately."""
-    N, C, H = PER_GPU_BATCH, 64, 16
-    t = _time_conv(device, 1, iters)
-    flops = 2.0 * N * H * H * C * C * 9
+def _conv_operands(device, H):
+    N, C = PER_GPU_BATCH, 64
+    x = torch.rand(N, C, H, H, device=device)
+    w = (torch.rand(C, C, 3, 3, device=device) - 0.5) * 0.1
+    b = torch.zeros(C, device=device)
+    return x, w, b
+
+
+def _mfma_record(kernel, label, t, flops, pmc_prefix, grid):
     ach = flops / t / 1e12
+    return {"kernel": f"{kernel} ({label})", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "launch_us": round(t * 1e6, 2),
+            "flops_per_launch": flops, "traffic": pmc_traffic(pmc_prefix, grid),
+            "traffic_unit": f"HBM bytes per launch (rocprofv3 PMC, profiles/{PMC_FILE})",
+            "step_share": step_share(pmc_prefix),
+            "step_share_source": f"share of in-step kernel time, profiles/{SHARE_FILE} (tools/step_share.py over the committed trace)"}
+
+
+def dominant_kernel_roofline(device, iters=30):
+    """The kernel with the largest share of in-step kernel time: conv_igemm_kernel<2, 3, 8, 1, 1, 1> (implicit GEMM by output
+    parity class: both transposed convs of the decoder and both stride-2 data gradients of the encoder, 4 launches per step),
+    timed alone on its heaviest shape, the 64->64 transposed conv 16x16 -> 32x32 at B = 256 with GELU and act' stores.
+    Algorithmic FLOPs: 2 * Cin * Cout * 9 per INPUT pixel = 4.83 GFLOP per launch."""
+    from gmk import ops
+    x, w, b = _conv_operands(device, 16)
+    t = _time_launches(lambda: ops.deconv2d_fwd(x, w, b, act="gelu", want_dact=True), iters)
+    flops = 2.0 * PER_GPU_BATCH * 16 * 16 * 64 * 64 * 9
+    return _mfma_record("conv_igemm_kernel<2, 3, 8, 1, 1, 1>", "transposed conv 64->64 3x3 s2, 16x16 -> 32x32, B256, gelu + act'",
+                        t, flops, "void conv_igemm_kernel<2, 3, 8, 1, 1, 1>", 262144)
+
+
+def igemm_s2_kernel_roofline(device, iters=30):
+    """Second of the implicit-GEMM class: the stride-2 conv (and the transposed conv's data gradient), 32x32 -> 16x16."""
+    from gmk import ops
+    x, w, b = _conv_operands(device, 32)
+    t = _time_launches(lambda: ops.conv2d_fwd(x, w, b, stride=2, act="gelu", want_dact=True), iters)
+    flops = 2.0 * PER_GPU_BATCH * 16 * 16 * 64 * 64 * 9
+    return _mfma_record("conv_igemm_kernel<1, 3, 8, 1, 2, 4>", "conv 64->64 3x3 s2, 32x32 -> 16x16, B256, gelu + act'",
+                        t, flops, "void conv_igemm_kernel<1, 3, 8, 1, 2, 4>", 131072)
+
+
+def wino_kernel_roofline(device, iters=30):
+    """The stride-1 16x16 layers (Winograd F(2x2,3x3), conv_wino.hip).  `achieved` / `frac` are ALGORITHMIC FLOPs (direct
+    convolution) over the launch time; the kernel executes 16/36 of those multiplies on the matrix cores:
+    `mfma_flops_executed` / `mfma_frac_executed` state that separately (`frac` is an effective-throughput figure whose
+    ceiling is 2.25, not 1)."""
+    from gmk import ops
+    x, w, b = _conv_operands(device, 16)
+    t = _time_launches(lambda: ops.conv2d_fwd(x, w, b, act="gelu", want_dact=True), iters)
+    flops = 2.0 * PER_GPU_BATCH * 16 * 16 * 64 * 64 * 9
     winograd = os.environ.get("GMK_WINO", "3") not in ("0", "2")
-    # HBM bytes per launch of this kernel/shape from the committed PMC passes (FETCH_SIZE doubled as the gfx950
-    # guide prescribes, + WRITE_SIZE; tools/prof_targets.py + tools/pmc_summary.py), null if the file is absent
-    traffic = pmc_traffic("void conv_wino_kernel<false>" if winograd else "void conv_igemm_kernel<0, 3, 8, 1, 2, 1>", 131072)
-    out = {"kernel": ("conv_wino_kernel<fwd> (Winograd F(2x2,3x3)" if winograd else "conv_igemm_kernel<S1,k3> (implicit GEMM")
-                     + ", 64->64 3x3 s1, 16x16, B256)",
-           "bound": "mfma", "achieved": round(ach, 2),
-           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-           "launch_us": round(t * 1e6, 2), "flops_per_launch": flops, "traffic": traffic,
-           "traffic_unit": f"HBM bytes per launch (rocprofv3 PMC, profiles/{PMC_FILE})"}
     if winograd:
+        out = _mfma_record("conv_wino_kernel<fwd>", "Winograd F(2x2,3x3), 64->64 3x3 s1, 16x16, B256, gelu + act'", t, flops,
+                           "void conv_wino_kernel<false>", 131072)
         out["mfma_flops_executed"] = flops * 16.0 / 36.0
-        out["mfma_frac_executed"] = round(ach * 16.0 / 36.0 / PEAK_F32_MFMA_TFLOPS, 4)
+        out["mfma_frac_executed"] = round(out["achieved"] * 16.0 / 36.0 / PEAK_F32_MFMA_TFLOPS, 4)
+    else:
+        out = _mfma_record("conv_igemm_kernel<0, 3, 8, 1, 2, 1>", "implicit GEMM, 64->64 3x3 s1, 16x16, B256, gelu + act'", t, flops,
+                           "void conv_igemm_kernel<0, 3, 8, 1, 2, 1>", 131072)
     return out
 
 
-def igemm_kernel_roofline(device, iters=30):
-    """The implicit-GEMM kernel class (conv_igemm_kernel: every stride-2 / transposed conv and their data gradients,
-    the largest share of the step) on its heaviest forward shape: 64->64 3x3 stride 2, 32x32 -> 16x16, B=256."""
-    N, C, OH = PER_GPU_BATCH, 64, 16
-    t = _time_conv(device, 2, iters)
-    flops = 2.0 * N * OH * OH * C * C * 9
-    ach = flops / t / 1e12
-    return {"kernel": "conv_igemm_kernel<S2,k3,64->64,32x32->16x16,B256>", "bound": "mfma", "achieved": round(ach, 2),
-            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-            "launch_us": round(t * 1e6, 2), "flops_per_launch": flops,
-            "traffic": pmc_traffic("void conv_igemm_kernel<1, 3, 8, 1, 2, 4>", 131072),
-            "traffic_unit": f"HBM bytes per launch (rocprofv3 PMC, profiles/{PMC_FILE})"}
-
-
-PMC_FILE = "r02_pmc_summary.json"
+PMC_FILE = "r03_pmc_summary.json"
+SHARE_FILE = "r03_step_share.json"
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 
 
@@ -115,6 +133,18 @@ def pmc_traffic(kernel_prefix, grid=None):
             for row in json.load(f):
                 if row["kernel"].startswith(kernel_prefix) and "hbm_read_B" in row and (grid is None or row.get("grid") == grid):
                     return round(row["hbm_read_B"] + row["hbm_write_B"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def step_share(kernel_prefix):
+    """Share of in-step kernel time of a kernel from the committed trace digest (tools/step_share.py), None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", SHARE_FILE)) as f:
+            for row in json.load(f)["kernels"]:
+                if row["kernel"].startswith(kernel_prefix):
+                    return row["share"]
     except (OSError, ValueError, KeyError):
         pass
     return None
@@ -147,6 +177,52 @@ def loss_kernel_roofline(device, B=65536, iters=10):
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "launch_us": round(t * 1e6, 1),
             "bytes_per_launch": nbytes, "traffic": pmc_traffic("void vae_loss_kernel<true, false, true>", B * 3072 // 4 if B * 3072 // 4 < 262144 else 262144),
             "traffic_unit": f"HBM bytes per launch (rocprofv3 PMC, profiles/{PMC_FILE})"}
+
+
+def secondary_config_leg(device, which, steps=10, warmup=3):
+    """Secondary workloads (not `value`): the train step of BASELINE.json configs[4] (VAE with pool + nearest upsample,
+    latent 512, synthetic 3x64x64, B = 256: 267.4 MFLOP forward, 788.0 MFLOP per image and step) and of
+    configs[0]'s shape at the reference's default batch (plain AE, B = 50, 313.39 MFLOP per image)."""
+    from models.autoencoders import Autoencoder
+    from utils import get_activation_function
+    from gmk.optim import FusedAdamW
+    if which == "cfg5":
+        kw = dict(variational=True, latent_size=512, no_pool=False, no_upsample=False, image_size=64)
+        B, hw, mflop, L = 256, 64, 788.0, 512
+        label = "VAE latent_size=512 --variational, pool + nearest upsample, act gelu, synthetic 3x64x64, batch 256 (BASELINE.json configs[4])"
+    else:
+        kw = dict(variational=False, latent_size=256, no_pool=True, no_upsample=True, image_size=32)
+        B, hw, mflop, L = 50, 32, 313.39, 256
+        label = "plain AE latent_size=256 --sigmoid --no_upsample --no_pool, act gelu, 3x32x32, batch 50 = the reference default (BASELINE.json configs[0] shape)"
+    torch.manual_seed(0)
+    model = Autoencoder(num_channels=64, kernel_size=3, act=get_activation_function("gelu"), sigmoid=True,
+                        interpolation="nearest", device=device, **kw).to(device)
+    optim = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(optim, T_max=100 * 196)
+    g = torch.Generator(device=device).manual_seed(99)
+    xs = [torch.rand(B, 3, hw, hw, device=device, generator=g) for _ in range(2)]
+
+    def step(i):
+        eps = torch.randn(B, L, device=device, generator=g) if kw["variational"] else None
+        losses = model.train_step(xs[i % 2], beta=5e-6, eps=eps)
+        optim.step()
+        sched.step()
+        return losses
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        losses = step(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"workload": label, "ms_per_step": round(dt * 1e3, 4), "images_per_sec": round(B / dt, 1), "steps": steps,
+           "mflop_per_image": mflop, "step_mfma_frac": round(B / dt * mflop * 1e6 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+           "final_total_loss": float(losses[2])}
+    del model, optim, xs
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(steps=6):
@@ -194,6 +270,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-fid", action="store_true", help="skip the FID-stats leg")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[4] (64x64, pool + upsample) and B=50 legs")
     args = ap.parse_args()
 
     from gmk.parallel import init_from_env, GradReducer, all_reduce_, broadcast_
@@ -276,8 +353,12 @@ def main():
             "step_mfma_frac": round(ips / world * TRAIN_MFLOP_PER_IMG * 1e6 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
         }
         out["roofline"] = dominant_kernel_roofline(device)
-        out["roofline_igemm"] = igemm_kernel_roofline(device)
+        out["roofline_igemm_s2"] = igemm_s2_kernel_roofline(device)
+        out["roofline_wino"] = wino_kernel_roofline(device)
         out["roofline_loss_kernel"] = loss_kernel_roofline(device)
+        if world == 1 and not args.no_secondary:
+            out["other_configs"] = {"cfg5_64x64_pool_upsample_latent512_b256": secondary_config_leg(device, "cfg5"),
+                                    "cfg1_shape_plain_ae_b50": secondary_config_leg(device, "cfg1", steps=50, warmup=10)}
     if not args.no_fid:
         try:
             from bench_fid import fid_stats_leg

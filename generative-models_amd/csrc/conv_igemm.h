@@ -16,6 +16,7 @@
 // channels and the matching weight slice are staged in LDS per K-chunk.
 #pragma once
 #include "gmk_common.h"
+#include <stdlib.h>
 
 struct ConvGeom {
   const float* x; const float* w; const float* bias; const float* dact_in;
@@ -292,10 +293,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
   const long long nq = Pq >> g.lgBHW;
   const int remq = (int)(Pq & (BHW - 1));
   const int byq = remq >> g.lgBW, bxq = remq & (g.BW - 1);
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-#pragma unroll
-    for (int py = 0; py < ((MODE == 2) ? 2 : 1); ++py) {
+  // (channel tile i, row parity py) passes, unrolled at compile time: with runtime loop indices the accumulator array
+  // of the MODE 2 / MT 2 variant was indexed dynamically and went to scratch memory
+  constexpr int NPY = (MODE == 2) ? 2 : 1;
+  gmk_static_for<0, MT * NPY>([&](auto ip_) {
+    constexpr int i = decltype(ip_)::value / NPY, py = decltype(ip_)::value % NPY;
+    {
       // bias of this lane's channels and, for dgrad, the act' factors of its rows: ALL fetched before the math, so the
       // HBM latency of the act' read is paid once per pass and not once per store instruction
       float bvs[32 / CPI];
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
         for (int it = 0; it < 32 / CPI; ++it) {
           const int c = ec + it * CPI;
           const int m = m0 + (wm * MT + i) * 32 + c;
-          if (m >= g.M || !pok) continue;
+          if (m >= g.M || !pok) continue;  // (inside store_rows' own loop)
           float4 v = *(const float4*)(Ew + c * ES + 4 * eq);
           const long long idx = idxs[it];
           if (g.epi == 0) {
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
       if (g.epi != 0) store_rows([](float z, float& a, float& d) { a = z; d = 1.f; });
       else GMK_WITH_ACT(g.act, store_rows)
     }
-  }
+  });
 }
 
 // Host-side launcher (one instantiation set per kernel size, defined in conv_igemm_k{3,5}.hip)
@@ -374,7 +377,10 @@ static int gmk_launch_conv_impl(ConvGeom& g, int mode, hipStream_t s) {
   //   against 64 x 64 the weight slice staged per chunk halves: 89 -> 65 us for the 16->32 transposed conv.
   int WM, MT;
   if (g.M <= 32) { WM = 1; MT = 1; }
-  else if (mode == 2) { WM = 1; MT = 1; }
+  else if (mode == 2) {
+    static const int m2mt2 = getenv("GMK_M2_MT2") ? atoi(getenv("GMK_M2_MT2")) : 0;   // A/B knob
+    WM = 1; MT = (m2mt2 && g.M > 32 && g.total_base / 128 >= 512) ? 2 : 1;
+  }
   else if (g.total_base / 128 >= 512) { WM = 1; MT = 2; }
   else if (mode == 0) { WM = 1; MT = 1; }
   else { WM = 2; MT = 1; }

@@ -83,10 +83,16 @@ def _load_cifar_batches(root, names):
     return torch.from_numpy(np.concatenate(xs)), torch.from_numpy(np.concatenate(ys))
 
 
-def get_cifar(dataset='cifar', data_dir='data', train_batch_size=50, test_batch_size=500, synthetic_size=(50000, 10000),
-              device=None, rank=0, world=1, seed=0):
-    """device = a CUDA device -> GPU-resident loaders (GpuCifarLoader); None / CPU -> torch DataLoaders over CPU tensors
+def get_cifar(dataset='CIFAR10', data_dir=None, num_samples=None, train_batch_size=None, test_batch_size=None,
+              synthetic_size=(50000, 10000), device=None, rank=0, world=1, seed=0):
+    """Signature of the reference (dataloaders.py:8: dataset, data_dir, num_samples, train_batch_size, test_batch_size, same
+    order and defaults; `num_samples` only acts in the reference's MNIST branch, dataloaders.py:14-18, and is accepted and
+    ignored here as it is there for CIFAR-10) plus keyword-only extras of this build.
+    device = a CUDA device -> GPU-resident loaders (GpuCifarLoader); None / CPU -> torch DataLoaders over CPU tensors
     (what the reference returns, dataloaders.py:37-43)."""
+    data_dir = 'data' if data_dir is None else data_dir
+    train_batch_size = 50 if train_batch_size is None else train_batch_size     # arguments.py:16-17 defaults
+    test_batch_size = 500 if test_batch_size is None else test_batch_size
     if str(dataset).lower() not in ('cifar', 'cifar10'):
         raise NotImplementedError(f'dataset {dataset!r}: only CIFAR-10 is on the path (the reference\'s MNIST branch is unused)')
     root = os.path.join(data_dir, 'cifar-10-batches-py')

@@ -121,6 +121,14 @@ def main(args):
         print(f'\n\nLoading model checkpoint from {args.checkpoint}')
         # reference checkpoints pickle `args` (with an nn.Module inside): not weights_only-loadable
         checkpoint = torch.load(args.checkpoint, weights_only=False)
+        # /root/reference/main.py:158-165: current against saved arguments, printed side by side
+        saved_args = checkpoint['args']
+        print(f'\n\nCurrent arguments:\n')
+        for current_arg in vars(args):
+            print(current_arg, getattr(args, current_arg))
+        print(f'\n\nCheckpoint arguments:\n')
+        for saved_arg in vars(saved_args):
+            print(saved_arg, getattr(saved_args, saved_arg))
 
     model = Autoencoder(variational=args.variational, latent_size=args.latent_size, num_channels=args.num_channels,
                         kernel_size=args.kernel_size, act=args.act_fn, sigmoid=args.sigmoid,

@@ -64,6 +64,47 @@ def test_b256_full_tensor_parity_and_8_shard_dp_equivalence(train_golden):
         assert np.allclose(p.detach().cpu().numpy(), ref.numpy(), rtol=1e-5, atol=2e-6), k
 
 
+def test_global_batch_2048_as_8_shards_of_256_matches_the_single_process_oracle(train_golden):
+    """BASELINE.json configs[2] at its stated size: the global batch of 2048 as 8 per-GPU shards of 256
+    (inputs / eps = slices of ONE B = 2048 batch), flat gradients summed as the SUM all-reduce leaves them, 1/8 applied by
+    the AdamW kernel, against the oracle's single-process B = 2048 step (/root/reference/main.py:31,45: batch means):
+    per-tensor rel-L2 <= 1e-4 on the gradients, then one AdamW step.  The weight-gradient reduction length here is 8x
+    that of any other parity case (2,097,152 pixels per weight for the 32x32 layers, split 8 ways + fixed-order slabs)."""
+    from gmk.optim import FusedAdamW
+    from test_model_gpu import build
+    case = dict(train_golden["vae_cfg2_b256"])
+    world, Bs = 8, 256
+    case["B"] = world * Bs
+    case["name"] = "vae_cfg2_dp2048"
+    params, x, eps = case_inputs(case)
+    beta = case["beta"]
+    o = ae_oracle.train_step_grads(params, x, eps, beta, oracle_cfg(case))
+    m = build(case, params)
+    opt = FusedAdamW(m.parameters(), lr=1e-3, weight_decay=0.01)
+    xt, et = torch.from_numpy(x).cuda(), torch.from_numpy(eps).cuda()
+    acc = torch.zeros_like(opt.flat_grad)
+    shard_losses = torch.zeros(3, dtype=torch.float64)
+    for r in range(world):
+        sl = slice(Bs * r, Bs * (r + 1))
+        shard_losses += m.train_step(xt[sl], beta=beta, eps=et[sl]).cpu().double()   # replays the launch plan from shard 1 on
+        acc += opt.flat_grad
+    mean_losses = shard_losses / world
+    assert abs(float(mean_losses[2]) - float(o["total"])) <= 1e-4 * float(o["total"])
+    assert abs(float(mean_losses[1]) - float(o["kl"])) <= 1e-4 * float(o["kl"])
+    opt.flat_grad.copy_(acc)
+    worst = 0.0
+    for k, p in m.named_parameters():
+        err = _rel(p.grad.cpu().numpy() / world, o["grads"][k].numpy())
+        worst = max(worst, err)
+        assert err <= 1e-4, (k, err)
+    opt.grad_scale = 1.0 / world
+    opt.step()
+    for k, p in m.named_parameters():
+        p0 = torch.from_numpy(params[k])
+        ref, _, _ = ae_oracle.adamw_step(p0, o["grads"][k], torch.zeros_like(p0), torch.zeros_like(p0), 1, 1e-3, 0.01)
+        assert np.allclose(p.detach().cpu().numpy(), ref.numpy(), rtol=1e-5, atol=2e-6), k
+
+
 def test_fid_and_is_statistics_are_shard_invariant():
     """configs[3]: partial (n, s, G) and softmax statistics of 8 uneven shards summed == one pass (<= 1e-12 relative)."""
     from gmk import ops

@@ -1,6 +1,6 @@
 """Launches the kernels BASELINE.json's north_star asks rocprof evidence for, a few times each, and nothing else:
    conv  : 64->64 3x3 at B=256 (+gelu, +act'): stride 1 at 16x16 (conv_wino_kernel; conv_igemm_kernel with GMK_WINO=0)
-           and stride 2 at 32x32 (conv_igemm_kernel)                                   -> MFMA utilisation
+           and stride 2 at 32x32 (conv_igemm_kernel); transposed conv 16->32 and 8->16       -> MFMA utilisation
    loss  : vae_loss_kernel at B=256 and B=65536 (fwd+bwd in one pass)                  -> HBM bytes / GB/s
    gram  : gram_partial128_kernel, X (50000 x 256) fp32 -> fp64 moments                -> MFMA (f64) utilisation, HBM bytes
    wgrad : conv_wgrad16_kernel, the three 3x3 weight-gradient shapes of the cfg-2 step  -> MFMA utilisation
@@ -25,6 +25,11 @@ if "conv" in which:
     for _ in range(REPS):
         ops.conv2d_fwd(x, w, b, act="gelu", want_dact=True)
         ops.conv2d_fwd(x32, w, b, stride=2, act="gelu", want_dact=True)
+    # the transposed conv (conv_igemm_kernel<2, ...>, the largest share of in-step kernel time) at both shapes of the step
+    x8 = torch.rand(256, 64, 8, 8, device=dev)
+    for _ in range(REPS):
+        ops.deconv2d_fwd(x, w, b, act="gelu", want_dact=True)      # 16x16 -> 32x32, grid 262144
+        ops.deconv2d_fwd(x8, w, b, act="gelu", want_dact=True)     # 8x8 -> 16x16, grid 65536
 if "loss" in which:
     for B in (256, 65536):
         pre = torch.randn(B, 3, 32, 32, device=dev)

@@ -8,7 +8,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 last = max(i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("adamw_kernel"))
 print("kernel,launches_in_roofline_leg,timed_launches,avg_us_timed,min_us,max_us")
-LEGS = (("void conv_wino_kernel<false>", "conv_wino_kernel<false> (64->64 3x3 s1, 16x16, B=256, gelu + act')"),
+LEGS = (("void conv_igemm_kernel<2, 3, 8, 1, 1, 1>", "conv_igemm_kernel<2, 3, 8, 1, 1, 1> (transposed conv 64->64 3x3 s2, 16x16->32x32, B=256, gelu + act')"),
+        ("void conv_wino_kernel<false>", "conv_wino_kernel<false> (64->64 3x3 s1, 16x16, B=256, gelu + act')"),
         ("void conv_igemm_kernel<0, 3, 8, 1, 2, 1>", "conv_igemm_kernel<0, 3, 8, 1, 2, 1> (64->64 3x3 s1, 16x16, B=256, gelu + act')"),
         ("void conv_igemm_kernel<1, 3, 8, 1, 2, 4>", "conv_igemm_kernel<1, 3, 8, 1, 2, 4> (64->64 3x3 s2, 32x32->16x16, B=256, gelu + act')"))
 for prefix, label in LEGS:
