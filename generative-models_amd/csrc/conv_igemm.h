@@ -30,7 +30,7 @@ struct ConvGeom {
   int act, epi;  // epi 0: +bias, act (and act' to dact_out); 1: * dact_in (dgrad)
   int seg_px, lg_seg_px, nseg;
   int PR, PC, PS, npos;
-  int dbg;  // ablation bits for profiling builds (0 in production): 1 = no epilogue stores, 2 = no K loop
+  int dbg;  // ablation bits for profiling builds (0 in production): 1 = no epilogue stores, 2 = no K loop, 4 = every chunk reloads chunk 0 (cache-resident operands, wrong results: the K loop without HBM latency)
 };
 
 #define CONV_MAXSLOT 4
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
     gmk_lds_barrier();  // buffer P is complete; everybody is done reading buffer P ^ 1 (reloads stay in flight)
     float* Xw = Xl + (P ^ 1) * XSZ;
     float* Ww = Wl + (P ^ 1) * MB * WS;
-    const int cn = (i + 2 < nch ? i + 2 : nch - 1) * CK;  // chunk to reload (uniform)
+    const int cn = (g.dbg & 4) ? 0 : (i + 2 < nch ? i + 2 : nch - 1) * CK;  // chunk to reload (uniform); dbg 4: always chunk 0
     int soffc[CK];
 #pragma unroll
     for (int c = 0; c < CK; ++c) soffc[c] = (cn + c) * IHW * 4;
@@ -377,10 +377,7 @@ static int gmk_launch_conv_impl(ConvGeom& g, int mode, hipStream_t s) {
   //   against 64 x 64 the weight slice staged per chunk halves: 89 -> 65 us for the 16->32 transposed conv.
   int WM, MT;
   if (g.M <= 32) { WM = 1; MT = 1; }
-  else if (mode == 2) {
-    static const int m2mt2 = getenv("GMK_M2_MT2") ? atoi(getenv("GMK_M2_MT2")) : 0;   // A/B knob
-    WM = 1; MT = (m2mt2 && g.M > 32 && g.total_base / 128 >= 512) ? 2 : 1;
-  }
+  else if (mode == 2) { WM = 1; MT = 1; }   // MT 2 (339 registers, one wave per SIMD) measured in round 3: 73 against 68 us
   else if (g.total_base / 128 >= 512) { WM = 1; MT = 2; }
   else if (mode == 0) { WM = 1; MT = 1; }
   else { WM = 2; MT = 1; }

@@ -137,6 +137,66 @@ __global__ __launch_bounds__(256) void ew_mul_kernel(const float* __restrict__ a
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) out[e] = a[e] * b[e];
 }
 
+// ---- vectorised fast paths (power-of-two widths, 16-byte aligned planes: every shape of the autoencoder path) ----------
+// One thread per FOUR output pixels of the pool / four input pixels of the nearest upsample: 16-byte loads and stores,
+// shifts instead of 64-bit divisions.  The generic kernels above took 1.6 TB/s (upsample forward) to 3.9 TB/s (pool forward)
+// on the 64x64 configuration (configs[4], 419 / 440 MB per step through them); same arithmetic, same results.
+__global__ __launch_bounds__(256) void maxpool2_fwd_v4_kernel(const float4* __restrict__ x, float4* __restrict__ y,
+                                                              unsigned* __restrict__ idx, long long nquads, int lgOWq, int W) {
+  const int OWq = 1 << lgOWq, Wq = W >> 2;   // output quads per row; input float4 per row
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nquads; q += (long long)gridDim.x * 256) {
+    const long long orow = q >> lgOWq;       // pl * OH + oy  ->  input rows 2 orow, 2 orow + 1
+    const int xq = (int)(q & (OWq - 1));
+    const float4* r0 = x + (2 * orow) * Wq + 2 * xq;
+    const float4 a0 = r0[0], a1 = r0[1], b0 = r0[Wq], b1 = r0[Wq + 1];
+    float4 o;
+    unsigned kk = 0;
+    auto one = [&](float p0, float p1, float p2, float p3, float& out, int sh) {
+      float best = p0; unsigned k = 0;
+      if (p1 > best || p1 != p1) { best = p1; k = 1; }
+      if (p2 > best || p2 != p2) { best = p2; k = 2; }
+      if (p3 > best || p3 != p3) { best = p3; k = 3; }
+      out = best; kk |= k << sh;
+    };
+    one(a0.x, a0.y, b0.x, b0.y, o.x, 0);
+    one(a0.z, a0.w, b0.z, b0.w, o.y, 8);
+    one(a1.x, a1.y, b1.x, b1.y, o.z, 16);
+    one(a1.z, a1.w, b1.z, b1.w, o.w, 24);
+    y[q] = o;
+    if (idx) idx[q] = kk;
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample2_nearest_fwd_v4_kernel(const float4* __restrict__ x, float4* __restrict__ y,
+                                                                       long long nquads, int lgWq) {
+  const int Wq = 1 << lgWq;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nquads; q += (long long)gridDim.x * 256) {
+    const long long row = q >> lgWq;         // pl * H + iy  ->  output rows 2 row, 2 row + 1 (2 Wq float4 each)
+    const int xq = (int)(q & (Wq - 1));
+    const float4 v = x[q];
+    const float4 a = make_float4(v.x, v.x, v.y, v.y), b = make_float4(v.z, v.z, v.w, v.w);
+    float4* o = y + (2 * row) * (2 * Wq) + 2 * xq;
+    o[0] = a; o[1] = b;
+    o[2 * Wq] = a; o[2 * Wq + 1] = b;
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample2_nearest_bwd_v4_kernel(const float4* __restrict__ dy, const float4* __restrict__ dact_in,
+                                                                       float4* __restrict__ dx, long long nquads, int lgWq) {
+  const int Wq = 1 << lgWq;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nquads; q += (long long)gridDim.x * 256) {
+    const long long row = q >> lgWq;
+    const int xq = (int)(q & (Wq - 1));
+    const float4* g = dy + (2 * row) * (2 * Wq) + 2 * xq;
+    const float4 a0 = g[0], a1 = g[1], b0 = g[2 * Wq], b1 = g[2 * Wq + 1];
+    // the generic kernel's summation order: (q[0] + q[1]) + (q[OW] + q[OW + 1])
+    float4 r = make_float4((a0.x + a0.y) + (b0.x + b0.y), (a0.z + a0.w) + (b0.z + b0.w),
+                           (a1.x + a1.y) + (b1.x + b1.y), (a1.z + a1.w) + (b1.z + b1.w));
+    if (dact_in) { const float4 d = dact_in[q]; r.x *= d.x; r.y *= d.y; r.z *= d.z; r.w *= d.w; }
+    dx[q] = r;
+  }
+}
+
 static inline int blocks_for(long long total) {
   long long b = (total + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -146,6 +206,13 @@ extern "C" int gmk_maxpool2_fwd(const float* x, float* y, unsigned char* idx, in
   GMK_PLAN_HOOK(gmk_maxpool2_fwd, x, y, idx, planes, H, W, stream);
   GMK_REQUIRE(x && y, GMK_E_NULL);
   GMK_REQUIRE(planes > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, GMK_E_SHAPE);
+  if (W % 8 == 0 && gmk_is_pow2(W) && gmk_aligned16(x) && gmk_aligned16(y) && (((uintptr_t)idx) & 3u) == 0) {
+    const long long nq = planes * (H / 2) * (W / 8);
+    hipLaunchKernelGGL(maxpool2_fwd_v4_kernel, dim3(blocks_for(nq)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (float4*)y,
+                       (unsigned*)idx, nq, gmk_ilog2(W / 8), W);
+    GMK_CHECK_LAUNCH();
+    return GMK_OK;
+  }
   hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(blocks_for(planes * (H / 2) * (W / 2))), dim3(256), 0, (hipStream_t)stream, x, y, idx, (long long)planes, H, W);
   GMK_CHECK_LAUNCH();
   return GMK_OK;
@@ -163,6 +230,13 @@ extern "C" int gmk_upsample2_fwd(const float* x, float* y, int64_t planes, int H
   GMK_REQUIRE(x && y, GMK_E_NULL);
   GMK_REQUIRE(planes > 0 && H >= 1 && W >= 1, GMK_E_SHAPE);
   GMK_REQUIRE(mode >= GMK_UP_NEAREST && mode <= GMK_UP_BICUBIC, GMK_E_UNSUPPORTED);
+  if (mode == GMK_UP_NEAREST && W % 4 == 0 && gmk_is_pow2(W) && gmk_aligned16(x) && gmk_aligned16(y)) {
+    const long long nq = planes * H * (W / 4);
+    hipLaunchKernelGGL(upsample2_nearest_fwd_v4_kernel, dim3(blocks_for(nq)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                       (float4*)y, nq, gmk_ilog2(W / 4));
+    GMK_CHECK_LAUNCH();
+    return GMK_OK;
+  }
   hipLaunchKernelGGL(upsample2_fwd_kernel, dim3(blocks_for(planes * 4 * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, (long long)planes, H, W, mode);
   GMK_CHECK_LAUNCH();
   return GMK_OK;
@@ -172,6 +246,13 @@ extern "C" int gmk_upsample2_bwd(const float* dy, const float* dact_in, float* d
   GMK_REQUIRE(dy && dx, GMK_E_NULL);
   GMK_REQUIRE(planes > 0 && H >= 1 && W >= 1, GMK_E_SHAPE);
   GMK_REQUIRE(mode >= GMK_UP_NEAREST && mode <= GMK_UP_BICUBIC, GMK_E_UNSUPPORTED);
+  if (mode == GMK_UP_NEAREST && W % 4 == 0 && gmk_is_pow2(W) && gmk_aligned16(dy) && gmk_aligned16(dx) && gmk_aligned16(dact_in)) {
+    const long long nq = planes * H * (W / 4);
+    hipLaunchKernelGGL(upsample2_nearest_bwd_v4_kernel, dim3(blocks_for(nq)), dim3(256), 0, (hipStream_t)stream, (const float4*)dy,
+                       (const float4*)dact_in, (float4*)dx, nq, gmk_ilog2(W / 4));
+    GMK_CHECK_LAUNCH();
+    return GMK_OK;
+  }
   hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(blocks_for(planes * H * W)), dim3(256), 0, (hipStream_t)stream, dy, dact_in, dx, (long long)planes, H, W, mode);
   GMK_CHECK_LAUNCH();
   return GMK_OK;

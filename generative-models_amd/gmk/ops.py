@@ -111,6 +111,8 @@ class SideQueue:
         # once the host stopped bounding the step (1 -> 2 -> 3 -> 4 streams: 1.056 / 1.021 / 1.021 / 1.040 ms; while the step was
         # host-bound, round 2 first measured two streams 1-3 % slower)
         n = max(1, int(os.environ.get("GMK_SIDE_STREAMS", "2")))
+        # (CU-masked side streams -- hipExtStreamCreateWithCUMask, 192 of 256 CUs -- were measured in round 3: 1.90 ms per step
+        # against 0.98, the masked queues serialise against the main one; not kept)
         self.streams = [torch.cuda.Stream(device, priority=prio) for _ in range(n)]
         self.stream = self.streams[0]
         self._next = 0

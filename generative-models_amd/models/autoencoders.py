@@ -323,8 +323,7 @@ class Autoencoder(nn.Module):
         the SAME tensors every step (losses, .stats, .latent_vector are overwritten in stream order): read or copy what
         you want to keep before the next step.  One plan is cached per model (a new key re-records).
         """
-        early = optimizer is not None and hasattr(optimizer, "step_range")
-        if early or os.environ.get("GMK_STEP_PLAN", "1") == "0" or torch.cuda.is_current_stream_capturing():
+        if os.environ.get("GMK_STEP_PLAN", "1") == "0" or torch.cuda.is_current_stream_capturing():
             return self._train_step_py(image, beta, mse_prior, eps, reducer, optimizer)
         from gmk.plan import StepPlan
         image = image.contiguous()
@@ -338,6 +337,8 @@ class Autoencoder(nn.Module):
         main_stream = torch.cuda.current_stream(image.device)
         self._step_tensors()
         dp = reducer is not None and reducer.world > 1
+        side = ops.side_queue(image.device)
+        early = self._early_ctx(optimizer, side, image.device, main_stream)
         key = (tuple(image.shape), float(beta), bool(mse_prior), main_stream.cuda_stream, dp, self._step_cache[3],
                bool(self.decoder.use_sigmoid), self.encoder._act_id, self.decoder._interp, os.environ.get("GMK_SIDE_WGRAD", "1"))
         cached = getattr(self, "_step_plan", None)
@@ -353,14 +354,15 @@ class Autoencoder(nn.Module):
             self._step_plan = (key, plan)
             return plan.out
         plan = cached[1]
-        if dp:
-            side = ops.side_queue(image.device)
+        if dp or early is not None:   # the host has work of its own between the segments
             a = 0
             for name, seg in plan.marks:
                 plan.enqueue(a, seg + 1, image, eps)
                 a = seg + 1
-                self._bucket_ready(name, reducer, side)
+                self._bucket_ready(name, reducer, side, early)
             plan.enqueue(a, plan.nseg, image, eps)
+            if early is not None:
+                main_stream.wait_stream(early[2])
         else:
             plan.enqueue(0, plan.nseg, image, eps)
         if self.variational:
@@ -368,17 +370,35 @@ class Autoencoder(nn.Module):
         self.latent_vector = plan.z
         return plan.out
 
+    def _early_ctx(self, optimizer, side, device, main_stream):
+        """(optimizer, bucket segments, update stream, main stream) for the bucket-wise early AdamW, or None."""
+        if optimizer is None or side is None or not hasattr(optimizer, "step_range"):
+            return None
+        return (optimizer, ops.bucket_segments(self, optimizer), ops.aux_stream(device), main_stream)
+
     @staticmethod
-    def _bucket_ready(name, reducer, side):
-        """Gradient bucket `name` is enqueued: start its all-reduce behind the weight-gradient streams."""
-        if reducer is None or reducer.world == 1:
-            return
-        if side is None:
-            reducer.ready(name)
-        else:  # the bucket's gradients are ordered on the side stream(s): the all-reduce waits for them
-            side.gather()
-            with torch.cuda.stream(side.stream):
+    def _bucket_ready(name, reducer, side, early=None):
+        """Gradient bucket `name` is enqueued: start its all-reduce behind the weight-gradient streams and, with `early`,
+        its AdamW update behind that."""
+        if reducer is not None and reducer.world > 1:
+            if side is None:
                 reducer.ready(name)
+            else:  # the bucket's gradients are ordered on the side stream(s): the all-reduce waits for them
+                side.gather()
+                with torch.cuda.stream(side.stream):
+                    reducer.ready(name)
+        if early is not None and name != "encoder.conv":
+            optimizer, seg, opt_stream, main_stream = early
+            # the update must follow the bucket's weight gradients (side stream), the kernels that read its weights
+            # (main stream, all enqueued by now) and its all-reduce
+            side.gather()
+            opt_stream.wait_stream(side.stream)
+            opt_stream.wait_stream(main_stream)
+            if reducer is not None:   # RCCL work handles order torch's current stream
+                with torch.cuda.stream(opt_stream):
+                    reducer.wait_bucket(name)
+            with ops.stream_scope(opt_stream):
+                optimizer.step_range(*seg[name])
 
     def _train_step_py(self, image, beta=0.0, mse_prior=False, eps=None, reducer=None, optimizer=None, rec=None):
         """The step launch by launch from Python (and the recording pass of a launch plan: `rec`)."""
@@ -415,26 +435,12 @@ class Autoencoder(nn.Module):
             if side is not None:
                 side.begin(main_stream)
 
-            early = optimizer is not None and side is not None and hasattr(optimizer, "step_range")
-            if early:
-                seg = ops.bucket_segments(self, optimizer)
-                opt_stream = ops.aux_stream(image.device)
+            early = self._early_ctx(optimizer, side, image.device, main_stream)
 
             def bucket_ready(name):
                 if rec is not None:
                     rec.mark(name)
-                self._bucket_ready(name, reducer, side)
-                if early and name != "encoder.conv":
-                    # the update must follow the bucket's weight gradients (side stream), the kernels that read its weights
-                    # (main stream, all enqueued by now) and its all-reduce
-                    side.gather()
-                    opt_stream.wait_stream(side.stream)
-                    opt_stream.wait_stream(main_stream)
-                    if reducer is not None:   # RCCL work handles order torch's current stream
-                        with torch.cuda.stream(opt_stream):
-                            reducer.wait_bucket(name)
-                    with ops.stream_scope(opt_stream):
-                        optimizer.step_range(*seg[name])
+                self._bucket_ready(name, reducer, side, early)
 
             rp = (stats, eps, float(beta) / B, mse_prior) if self.variational else None
             _, dz = engine.decoder_backward(pd, svd, dpre, no_upsample=dec.no_upsample, interpolation=dec._interp,
@@ -446,6 +452,6 @@ class Autoencoder(nn.Module):
             bucket_ready("encoder.conv")
             if side is not None:
                 side.join()
-        if early:
-            main_stream.wait_stream(opt_stream)
+        if early is not None:
+            main_stream.wait_stream(early[2])
         return losses

@@ -253,7 +253,7 @@ def test_vae_loss_fwd_bwd(B, sigmoid, variational, mse_prior):
     close(rout, recon, name="recon")
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 16, 16), (3, 5, 32, 32), (1, 4, 8, 8)])
+@pytest.mark.parametrize("shape", [(2, 8, 16, 16), (3, 5, 32, 32), (1, 4, 8, 8), (2, 3, 64, 64), (1, 2, 12, 12)])   # 12: the generic (non power-of-two) kernel
 def test_maxpool2(shape):
     from gmk import ops
     x = T(f"mp{shape}", shape).double().requires_grad_(True)
@@ -275,7 +275,7 @@ def test_maxpool2(shape):
 
 
 @pytest.mark.parametrize("mode", ["nearest", "bilinear", "bicubic"])
-@pytest.mark.parametrize("shape", [(2, 8, 8, 8), (1, 3, 16, 16), (2, 2, 4, 4)])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 8), (1, 3, 16, 16), (2, 2, 4, 4), (2, 3, 32, 32), (1, 2, 6, 6)])   # 6: the generic nearest kernel
 def test_upsample2(mode, shape):
     from gmk import ops
     x = T(f"up{shape}", shape).double().requires_grad_(True)
