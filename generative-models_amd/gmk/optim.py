@@ -30,6 +30,8 @@ class FusedAdamW(torch.optim.AdamW):
             raise NotImplementedError("FusedAdamW supports a single param group (the reference uses one)")
         self.grad_scale = 1.0  # set to 1/world_size by the DP reducer (SUM all-reduce)
         self._early = []       # flat ranges already updated by step_range() for the step in progress
+        self._t = 0            # optimizer steps taken (= the shared state['step'] tensor)
+        self._state_ready = False
         self._flatten()
 
     # ------------------------------------------------------------------ flat storage
@@ -73,6 +75,19 @@ class FusedAdamW(torch.optim.AdamW):
                 return False
         return True
 
+    def _views_ok_fast(self):
+        """The per-step check: every parameter still has a gradient and the first and last still sit in the flat buffers
+        (model.to() / load_state_dict re-home all of them together); the full walk costs 20 us of host time per step."""
+        ps = self.param_groups[0]["params"]
+        for p in ps:
+            if p.grad is None:
+                return False
+        base_p, base_g = self.flat_param.data_ptr(), self.flat_grad.data_ptr()
+        for p, o in ((ps[0], self._offsets[0]), (ps[-1], self._offsets[-1])):
+            if p.data_ptr() != base_p + 4 * o or p.grad.data_ptr() != base_g + 4 * o:
+                return False
+        return True
+
     def segment(self, params):
         """(start, end) float offsets of the flat range spanned by `params` (must be contiguous in order)."""
         ps = self.param_groups[0]["params"]
@@ -91,23 +106,32 @@ class FusedAdamW(torch.optim.AdamW):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        self._state_ready = False   # the step count is re-read from the loaded state['step']
         self._flatten()
 
     def _prepare(self):
-        if not self._views_ok():
+        if not self._views_ok_fast() or (self._t % 64 == 0 and not self._views_ok()):
             self._flatten()  # someone re-assigned p.data / p.grad (e.g. model.to()): re-home them
         group = self.param_groups[0]
         ps = group["params"]
         if self.flat_param.device.type != "cuda":
             raise RuntimeError("FusedAdamW.step() runs a gfx950 kernel: parameters must be on an MI355X (no CPU path)")
-        # state['step'] bookkeeping exactly like torch (a float32 scalar tensor per parameter)
-        for p, o in zip(ps, self._offsets):
-            st = self.state[p]
-            if len(st) == 0:
-                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+        if not self._state_ready:
+            # state['step'] bookkeeping like torch (a float32 scalar tensor per parameter) -- except that all parameters
+            # share ONE tensor object: bumping 24 separate CPU tensors every step cost 50 us of host time.  state_dict()
+            # still shows a 'step' per parameter, and a stock torch.optim.AdamW that loads it makes its own copies.
+            first = self.state[ps[0]]
+            t0 = float(first["step"]) if "step" in first else 0.0
+            self._step_t = torch.tensor(t0, dtype=torch.float32)
+            for p, o in zip(ps, self._offsets):
+                st = self.state[p]
                 n = p.numel()
-                st["exp_avg"] = self.flat_m[o:o + n].view(p.shape)
-                st["exp_avg_sq"] = self.flat_v[o:o + n].view(p.shape)
+                if "exp_avg" not in st:
+                    st["exp_avg"] = self.flat_m[o:o + n].view(p.shape)
+                    st["exp_avg_sq"] = self.flat_v[o:o + n].view(p.shape)
+                st["step"] = self._step_t
+            self._t = int(t0)
+            self._state_ready = True
         return group, ps
 
     def _launch(self, group, a, b, step):
@@ -124,17 +148,16 @@ class FusedAdamW(torch.optim.AdamW):
         Autoencoder.train_step(optimizer=...) update a gradient bucket as soon as it is final, under the rest of backward
         (same arithmetic, same step number, same lr as the step() that follows)."""
         group, ps = self._prepare()
-        step = int(self.state[ps[0]]["step"].item()) + 1
-        self._launch(group, a, b, step)
+        self._launch(group, a, b, self._t + 1)
         self._early.append((a, b))
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         group, ps = self._prepare()
-        for p in ps:
-            self.state[p]["step"] += 1
-        step = int(self.state[ps[0]]["step"].item())
+        self._t += 1
+        self._step_t += 1
+        step = self._t
         pos = 0
         for a, b in sorted(self._early) + [(self._numel, self._numel)]:   # the complement of the early ranges
             if a > pos:
