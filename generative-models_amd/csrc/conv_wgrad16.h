@@ -359,4 +359,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_nolds_kernel(const floa
   }
 }
 
-int gmk_launch_wgrad16(WgradGeom& g, int sb, float* dw, float* dbias, hipStream_t s);
+int gmk_launch_wgrad16(WgradGeom& g, int sb, float* dw, float* dbias, hipStream_t s);   // dw == nullptr: slabs only (deferred reduction)
+
+// deferred reduction of up to GMK_WG16_BATCH layers' slabs in one launch
+#define GMK_WG16_BATCH 8
+struct Wg16ReduceItem { const float* slab; float* dw; float* dbias; int G, ny, Cs, Cb, cbT, bias_mode; };
+struct Wg16ReduceBatch { Wg16ReduceItem item[GMK_WG16_BATCH]; };
+int gmk_launch_wgrad16_reduce_batch(const Wg16ReduceBatch& b, int n, int max_ny, hipStream_t s);

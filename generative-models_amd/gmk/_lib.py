@@ -34,6 +34,8 @@ SIGNATURES = {
     "gmk_conv2d_dgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "gmk_conv2d_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
     "gmk_conv2d_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "gmk_conv_wgrad_can_defer": (_I, [_I, _I, _I, _I, _I, _I, _I, _I]),
+    "gmk_conv_wgrad_reduce_batch": (_I, [_P, _I, _P]),
     "gmk_deconv2d_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "gmk_deconv2d_dgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "gmk_deconv2d_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
@@ -64,6 +66,14 @@ SIGNATURES = {
     "gmk_vae_loss_fwd_bwd_fused": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _F, _I, _P, _Z, _P, _P]),
     "gmk_vae_loss_eval": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _F, _I, _P, _Z, _P]),
 }
+
+
+
+class WgradLayer(C.Structure):
+    """gmk_wgrad_layer of include/gmk.h (one entry of gmk_conv_wgrad_reduce_batch)."""
+    _fields_ = [("ws", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p), ("N", _I), ("Cin", _I), ("H", _I), ("W", _I),
+                ("Cout", _I), ("ksize", _I), ("stride", _I), ("transposed", _I)]
+
 
 _lib = None
 

@@ -66,9 +66,10 @@ def encoder_forward(p, x, *, act, no_pool, ksize, train, reparam_eps=None):
     return out, sv
 
 
-def encoder_backward(p, sv, dout, *, no_pool, ksize, gout=None, on_fc_done=None, side=None, need_dx=False):
+def encoder_backward(p, sv, dout, *, no_pool, ksize, gout=None, on_fc_done=None, side=None, need_dx=False, defer=None):
     """dout: (B, mult*L) gradient of the encoder output.  Returns param grads (+ "__dx__", the gradient w.r.t. the
-    input image, when need_dx)."""
+    input image, when need_dx).  defer: list collecting the layers whose slab reduction is left to ONE later
+    ops.wgrad_reduce_batch() launch (train_step: per gradient bucket)."""
     g = {}
     B = dout.shape[0]
     x = sv["x"]
@@ -79,23 +80,23 @@ def encoder_backward(p, sv, dout, *, no_pool, ksize, gout=None, on_fc_done=None,
         # fc gradients are enqueued and the last reader of fc.weight (the dgrad above) is too: the bucket's all-reduce
         # -- and its early AdamW update -- can start under the conv backward
         on_fc_done()
-    g["conv3.weight"], g["conv3.bias"] = _wg(side, lambda: ops.conv2d_wgrad(dz5, sv["a4"], ksize, 1, out=_o(gout, "conv3")), dz5)
+    g["conv3.weight"], g["conv3.bias"] = _wg(side, lambda: ops.conv2d_wgrad(dz5, sv["a4"], ksize, 1, out=_o(gout, "conv3"), defer=defer), dz5)
     if no_pool:
         dz4 = ops.conv2d_dgrad(dz5, p["conv3.weight"], tuple(sv["a4"].shape), 1, dact_in=sv["d4"])
-        g["downsample2.weight"], g["downsample2.bias"] = _wg(side, lambda: ops.conv2d_wgrad(dz4, sv["a3"], ksize, 2, out=_o(gout, "downsample2")), dz4)
+        g["downsample2.weight"], g["downsample2.bias"] = _wg(side, lambda: ops.conv2d_wgrad(dz4, sv["a3"], ksize, 2, out=_o(gout, "downsample2"), defer=defer), dz4)
         dz3 = ops.conv2d_dgrad(dz4, p["downsample2.weight"], tuple(sv["a3"].shape), 2, dact_in=sv["d3"])
     else:
         da4 = ops.conv2d_dgrad(dz5, p["conv3.weight"], tuple(sv["a4"].shape), 1)
         dz3 = ops.maxpool2_bwd(da4, sv["i2"], dact_in=sv["d3"])
-    g["conv2.weight"], g["conv2.bias"] = _wg(side, lambda: ops.conv2d_wgrad(dz3, sv["a2"], ksize, 1, out=_o(gout, "conv2")), dz3)
+    g["conv2.weight"], g["conv2.bias"] = _wg(side, lambda: ops.conv2d_wgrad(dz3, sv["a2"], ksize, 1, out=_o(gout, "conv2"), defer=defer), dz3)
     if no_pool:
         dz2 = ops.conv2d_dgrad(dz3, p["conv2.weight"], tuple(sv["a2"].shape), 1, dact_in=sv["d2"])
-        g["downsample1.weight"], g["downsample1.bias"] = _wg(side, lambda: ops.conv2d_wgrad(dz2, sv["a1"], ksize, 2, out=_o(gout, "downsample1")), dz2)
+        g["downsample1.weight"], g["downsample1.bias"] = _wg(side, lambda: ops.conv2d_wgrad(dz2, sv["a1"], ksize, 2, out=_o(gout, "downsample1"), defer=defer), dz2)
         dz1 = ops.conv2d_dgrad(dz2, p["downsample1.weight"], tuple(sv["a1"].shape), 2, dact_in=sv["d1"])
     else:
         da2 = ops.conv2d_dgrad(dz3, p["conv2.weight"], tuple(sv["a2"].shape), 1)
         dz1 = ops.maxpool2_bwd(da2, sv["i1"], dact_in=sv["d1"])
-    g["conv1.weight"], g["conv1.bias"] = _wg(side, lambda: ops.conv2d_wgrad(dz1, x, ksize, 1, out=_o(gout, "conv1")), dz1)
+    g["conv1.weight"], g["conv1.bias"] = _wg(side, lambda: ops.conv2d_wgrad(dz1, x, ksize, 1, out=_o(gout, "conv1"), defer=defer), dz1)
     if need_dx:
         g["__dx__"] = ops.conv2d_dgrad(dz1, p["conv1.weight"], tuple(x.shape), 1)
     return g
@@ -138,29 +139,29 @@ def decoder_forward(p, z, *, act, num_channels, no_upsample, interpolation, ksiz
     return out, sv
 
 
-def decoder_backward(p, sv, dpre, *, no_upsample, interpolation, ksize, need_dz=True, gout=None, side=None, reparam=None):
+def decoder_backward(p, sv, dpre, *, no_upsample, interpolation, ksize, need_dz=True, gout=None, side=None, reparam=None, defer=None):
     """dpre: gradient w.r.t. conv3's pre-activation output (B,3,H,W).  Returns (param grads, dz).
     reparam = (stats, eps, kl_scale, mse_prior): the fc dgrad is fused with the reparameterisation backward and the
     beta*KL gradient (gmk_linear_dgrad_reparam) and the second return value is dstats (B, L, 2) instead of dz."""
     g = {}
     B = dpre.shape[0]
-    g["conv3.weight"], g["conv3.bias"] = _wg(side, lambda: ops.conv2d_wgrad(dpre, sv["h4"], ksize, 1, out=_o(gout, "conv3")), dpre)
+    g["conv3.weight"], g["conv3.bias"] = _wg(side, lambda: ops.conv2d_wgrad(dpre, sv["h4"], ksize, 1, out=_o(gout, "conv3"), defer=defer), dpre)
     if no_upsample:
         dz4 = ops.conv2d_dgrad(dpre, p["conv3.weight"], tuple(sv["h4"].shape), 1, dact_in=sv["e4"])
-        g["deconv2.weight"], g["deconv2.bias"] = _wg(side, lambda: ops.deconv2d_wgrad(dz4, sv["h3"], ksize, out=_o(gout, "deconv2")), dz4)
+        g["deconv2.weight"], g["deconv2.bias"] = _wg(side, lambda: ops.deconv2d_wgrad(dz4, sv["h3"], ksize, out=_o(gout, "deconv2"), defer=defer), dz4)
         dz3 = ops.deconv2d_dgrad(dz4, p["deconv2.weight"], tuple(sv["h3"].shape), dact_in=sv["e3"])
     else:
         dh4 = ops.conv2d_dgrad(dpre, p["conv3.weight"], tuple(sv["h4"].shape), 1)
         dz3 = ops.upsample2_bwd(dh4, interpolation, dact_in=sv["e3"])
-    g["conv2.weight"], g["conv2.bias"] = _wg(side, lambda: ops.conv2d_wgrad(dz3, sv["h2"], ksize, 1, out=_o(gout, "conv2")), dz3)
+    g["conv2.weight"], g["conv2.bias"] = _wg(side, lambda: ops.conv2d_wgrad(dz3, sv["h2"], ksize, 1, out=_o(gout, "conv2"), defer=defer), dz3)
     if no_upsample:
         dz2 = ops.conv2d_dgrad(dz3, p["conv2.weight"], tuple(sv["h2"].shape), 1, dact_in=sv["e2"])
-        g["deconv1.weight"], g["deconv1.bias"] = _wg(side, lambda: ops.deconv2d_wgrad(dz2, sv["h1"], ksize, out=_o(gout, "deconv1")), dz2)
+        g["deconv1.weight"], g["deconv1.bias"] = _wg(side, lambda: ops.deconv2d_wgrad(dz2, sv["h1"], ksize, out=_o(gout, "deconv1"), defer=defer), dz2)
         dz1 = ops.deconv2d_dgrad(dz2, p["deconv1.weight"], tuple(sv["h1"].shape), dact_in=sv["e1"])
     else:
         dh2 = ops.conv2d_dgrad(dz3, p["conv2.weight"], tuple(sv["h2"].shape), 1)
         dz1 = ops.upsample2_bwd(dh2, interpolation, dact_in=sv["e1"])
-    g["conv1.weight"], g["conv1.bias"] = _wg(side, lambda: ops.conv2d_wgrad(dz1, sv["h0v"], ksize, 1, out=_o(gout, "conv1")), dz1)
+    g["conv1.weight"], g["conv1.bias"] = _wg(side, lambda: ops.conv2d_wgrad(dz1, sv["h0v"], ksize, 1, out=_o(gout, "conv1"), defer=defer), dz1)
     dz0 = ops.conv2d_dgrad(dz1, p["conv1.weight"], tuple(sv["h0v"].shape), 1, dact_in=sv["e0"].view_as(sv["h0v"]))
     dz0 = dz0.view(B, -1)
     g["fc.weight"], g["fc.bias"] = _wg(side, lambda: ops.linear_wgrad(dz0, sv["z"], out=_o(gout, "fc")), dz0)

@@ -141,6 +141,19 @@ class SideQueue:
         finally:
             _cur_stream = prev
 
+    def reduce_batch(self, items):
+        """The deferred slab reductions of a gradient bucket in one launch on streams[0], behind the weight-gradient kernels
+        of every side stream (forks through gmk_stream_wait_stream so that a launch plan records them)."""
+        global _cur_stream
+        for h in self._handles[1:]:
+            check(lib().gmk_stream_wait_stream(self._handles[0], h))
+        prev = _cur_stream
+        _cur_stream = self._handles[0]
+        try:
+            wgrad_reduce_batch(items)
+        finally:
+            _cur_stream = prev
+
     def gather(self):
         """Orders streams[0] behind the other side streams (so that work enqueued on it next, e.g. a gradient bucket's
         all-reduce, sees every weight gradient launched so far)."""
@@ -215,11 +228,46 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, dact_in=None):
     return dx
 
 
-def conv2d_wgrad(dy, x, ksize, stride=1, want_bias=True, out=None):
-    """out: optional (dw, db) tensors to write into (e.g. views of a flat gradient buffer)."""
+_layer_ws = {}
+
+
+def _layer_workspace(key, nbytes, device):
+    """A workspace of a layer's own (deferred slab reduction: the slabs must survive until the bucket's batch reduce), keyed
+    by the layer's gradient destination; grown buffers are retired like the shared ones (workspace())."""
+    ws = _layer_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if ws is not None:
+            _ws_retired.append(ws)
+        ws = _layer_ws[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    return ws
+
+
+def wgrad_reduce_batch(items):
+    """One launch summing the slabs of the deferred weight gradients in `items` (conv2d_wgrad / deconv2d_wgrad, defer=)."""
+    from ._lib import WgradLayer
+    for a in range(0, len(items), 8):
+        chunk = items[a:a + 8]
+        arr = (WgradLayer * len(chunk))()
+        for k, (ws, dw, db, geo) in enumerate(chunk):
+            arr[k] = WgradLayer(ws.data_ptr(), dw.data_ptr(), _p(db), *geo)
+        check(lib().gmk_conv_wgrad_reduce_batch(arr, len(chunk), _stream()))
+
+
+def conv2d_wgrad(dy, x, ksize, stride=1, want_bias=True, out=None, defer=None):
+    """out: optional (dw, db) tensors to write into (e.g. views of a flat gradient buffer).
+    defer: a list -> where the library can (gmk_conv_wgrad_can_defer) only the partial slabs are written now, into a workspace
+    of the layer's own, and (ws, dw, db, geometry) is appended for a later wgrad_reduce_batch(); needs `out`."""
     _chk(dy, x)
     N, Cin, H, W = x.shape
     Cout = dy.shape[1]
+    if defer is not None and out is not None and lib().gmk_conv_wgrad_can_defer(N, Cin, H, W, Cout, ksize, stride, 0):
+        dw, db = out
+        _chk(dw, db)
+        nb = lib().gmk_conv2d_wgrad_workspace_bytes(N, Cin, H, W, Cout, ksize, stride)
+        ws = _layer_workspace(dw.data_ptr(), nb, x.device)
+        check(lib().gmk_conv2d_wgrad(_p(dy), _p(x), None, _p(db), N, Cin, H, W, Cout, ksize, stride, _p(ws), ws.numel(), _stream()))
+        defer.append((ws, dw, db, (N, Cin, H, W, Cout, ksize, stride, 0)))
+        return dw, db
     if out is not None:
         dw, db = out
         _chk(dw, db)
@@ -251,10 +299,18 @@ def deconv2d_dgrad(dy, w, x_shape, dact_in=None):
     return dx
 
 
-def deconv2d_wgrad(dy, x, ksize, want_bias=True, out=None):
+def deconv2d_wgrad(dy, x, ksize, want_bias=True, out=None, defer=None):
     _chk(dy, x)
     N, Cin, H, W = x.shape
     Cout = dy.shape[1]
+    if defer is not None and out is not None and lib().gmk_conv_wgrad_can_defer(N, Cin, H, W, Cout, ksize, 2, 1):
+        dw, db = out
+        _chk(dw, db)
+        nb = lib().gmk_deconv2d_wgrad_workspace_bytes(N, Cin, H, W, Cout, ksize)
+        ws = _layer_workspace(dw.data_ptr(), nb, x.device)
+        check(lib().gmk_deconv2d_wgrad(_p(dy), _p(x), None, _p(db), N, Cin, H, W, Cout, ksize, _p(ws), ws.numel(), _stream()))
+        defer.append((ws, dw, db, (N, Cin, H, W, Cout, ksize, 2, 1)))
+        return dw, db
     if out is not None:
         dw, db = out
         _chk(dw, db)

@@ -340,7 +340,8 @@ class Autoencoder(nn.Module):
         side = ops.side_queue(image.device)
         early = self._early_ctx(optimizer, side, image.device, main_stream)
         key = (tuple(image.shape), float(beta), bool(mse_prior), main_stream.cuda_stream, dp, self._step_cache[3],
-               bool(self.decoder.use_sigmoid), self.encoder._act_id, self.decoder._interp, os.environ.get("GMK_SIDE_WGRAD", "1"))
+               bool(self.decoder.use_sigmoid), self.encoder._act_id, self.decoder._interp, os.environ.get("GMK_SIDE_WGRAD", "1"),
+               os.environ.get("GMK_DEFER_REDUCE", "0"))
         cached = getattr(self, "_step_plan", None)
         if cached is None or cached[0] != key:
             if cached is not None:      # frees the old plan's activations before the new recording allocates its own
@@ -442,13 +443,28 @@ class Autoencoder(nn.Module):
                     rec.mark(name)
                 self._bucket_ready(name, reducer, side, early)
 
+            # GMK_DEFER_REDUCE=1: the slab reductions of the 3x3 weight gradients are left to ONE launch per gradient bucket
+            # (gmk_conv_wgrad_reduce_batch: 8 reduce launches -> 2).  Bit-identical; measured 1.037 against 1.026 ms per step
+            # in the same call (the gradients of a whole bucket become final later), so it is off by default
+            dfr = [] if os.environ.get("GMK_DEFER_REDUCE", "0") != "0" else None
+
+            def flush_reduces():
+                if dfr:
+                    if side is not None:
+                        side.reduce_batch(dfr)
+                    else:
+                        ops.wgrad_reduce_batch(dfr)
+                    del dfr[:]
+
             rp = (stats, eps, float(beta) / B, mse_prior) if self.variational else None
             _, dz = engine.decoder_backward(pd, svd, dpre, no_upsample=dec.no_upsample, interpolation=dec._interp,
-                                            ksize=dec.kernel_size, need_dz=True, gout=gd, side=side, reparam=rp)
+                                            ksize=dec.kernel_size, need_dz=True, gout=gd, side=side, reparam=rp, defer=dfr)
+            flush_reduces()
             bucket_ready("decoder")
             dout = dz.view(B, -1)
             engine.encoder_backward(pe, sve, dout, no_pool=enc.no_pool, ksize=enc.kernel_size, gout=ge,
-                                    on_fc_done=lambda: bucket_ready("encoder.fc"), side=side)
+                                    on_fc_done=lambda: bucket_ready("encoder.fc"), side=side, defer=dfr)
+            flush_reduces()
             bucket_ready("encoder.conv")
             if side is not None:
                 side.join()

@@ -135,6 +135,20 @@ int gmk_conv2d_wgrad(const float* dy, const float* x, float* dw, float* dbias,
                      int N, int Cin, int H, int W, int Cout, int ksize, int stride,
                      void* ws, size_t ws_bytes, gmk_stream_t stream);
 
+/* Deferred slab reduction (round 3; no counterpart in the reference: it is how autograd's per-layer weight gradients,
+ *   main.py:51, are scheduled here).  gmk_conv2d_wgrad / gmk_deconv2d_wgrad with dw == NULL write only their partial slabs
+ *   into `ws` (which must then be the layer's own, kept until reduced) -- for the layers where gmk_conv_wgrad_can_defer()
+ *   returns 1 (3x3, the widths of the 16x16x4-MFMA kernel; others return GMK_E_UNSUPPORTED); gmk_conv_wgrad_reduce_batch
+ *   then sums the slabs of up to 8 such layers in ONE launch, in the same fixed order as the per-layer reduction (bit-identical
+ *   dw / dbias).  `layers`: host array; each entry repeats the layer's geometry as passed to the weight-gradient call
+ *   (transposed = 1: the arguments of gmk_deconv2d_wgrad, stride 2).  dbias may be NULL. */
+typedef struct gmk_wgrad_layer {
+  const void* ws; float* dw; float* dbias;
+  int N, Cin, H, W, Cout, ksize, stride, transposed;
+} gmk_wgrad_layer;
+int gmk_conv_wgrad_can_defer(int N, int Cin, int H, int W, int Cout, int ksize, int stride, int transposed);
+int gmk_conv_wgrad_reduce_batch(const gmk_wgrad_layer* layers, int n, gmk_stream_t stream);
+
 /* Transposed convolution, stride 2, padding (k-1)/2, output_padding 1: (H,W) -> (2H,2W).
  *   replaces nn.ConvTranspose2d + activation, models/autoencoders.py:86-87,100,104
  *   x (N,Cin,H,W)  w (Cin,Cout,k,k)  y,dact (N,Cout,2H,2W) */

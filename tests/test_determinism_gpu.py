@@ -133,3 +133,37 @@ def test_first_step_from_cold_workspaces_matches_the_single_stream_step(monkeypa
     m1.train_step(x, beta=5e-6, eps=eps)
     torch.cuda.synchronize()
     assert torch.equal(o1.flat_grad, ref), float((o1.flat_grad - ref).abs().max())
+
+
+@pytest.mark.parametrize("cfg", [dict(B=256), dict(B=24, kernel_size=5), dict(B=16, no_pool=False, no_upsample=False), dict(B=8, plan="0")])
+def test_deferred_batch_reduce_is_bit_identical_to_per_layer_reduces(monkeypatch, cfg):
+    """gmk_conv_wgrad_reduce_batch (one slab-reduce launch per gradient bucket) against the per-layer reduce launches: same
+    slabs, same fixed summation order, so the same bits -- with the launch plan and without, on the 3x3 layers that defer and
+    on configurations whose layers cannot (5x5 kernels: per-layer path; pool / upsample variant)."""
+    from models.autoencoders import Autoencoder
+    from utils import get_activation_function
+    from gmk.optim import FusedAdamW
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("GMK_STEP_PLAN", cfg.get("plan", "1"))
+    g = torch.Generator(device=dev).manual_seed(17)
+    B = cfg["B"]
+    xs = [torch.rand(B, 3, 32, 32, device=dev, generator=g) for _ in range(3)]
+    es = [torch.randn(B, 256, device=dev, generator=g) for _ in range(3)]
+    res = []
+    for defer in ("0", "1"):
+        monkeypatch.setenv("GMK_DEFER_REDUCE", defer)
+        torch.manual_seed(0)
+        m = Autoencoder(variational=True, latent_size=256, num_channels=64, kernel_size=cfg.get("kernel_size", 3),
+                        act=get_activation_function("gelu"), sigmoid=True, interpolation="nearest",
+                        no_pool=cfg.get("no_pool", True), no_upsample=cfg.get("no_upsample", True), device=dev).to(dev)
+        opt = FusedAdamW(m.parameters(), lr=1e-3, weight_decay=0.01)
+        out = []
+        for x, e in zip(xs, es):      # step 1 records (plan on), steps 2-3 replay
+            losses = m.train_step(x, beta=5e-6, eps=e)
+            torch.cuda.synchronize()
+            out.append((opt.flat_grad.clone(), losses.clone()))
+            opt.step()
+        res.append(out)
+    for (ga, la), (gb, lb) in zip(*res):
+        assert torch.equal(la, lb)
+        assert torch.equal(ga, gb), float((ga - gb).abs().max())
