@@ -167,3 +167,20 @@ extern "C" int gmk_deconv2d_dgrad(const float* dy, const float* w, const float* 
   g.w_numel = Cout * Cin * KK;
   return dispatch(g, ksize, 1, (hipStream_t)stream);
 }
+
+#ifdef GMK_CONV_TRACE
+// tools-only build (make EXTRA=-DGMK_CONV_TRACE): per-block timestamps of the LAST implicit-GEMM launch
+static unsigned long long* g_trace = nullptr;
+unsigned long long* gmk_conv_trace_buffer() {
+  if (!g_trace) { if (hipMalloc((void**)&g_trace, 12 * 8 * 65536) != hipSuccess) g_trace = nullptr; }
+  return g_trace;
+}
+extern "C" int gmk_debug_conv_trace_read(unsigned long long* dst, int nblocks) {
+  if (!g_trace || nblocks > 65536) return -1;
+  return (int)hipMemcpy(dst, g_trace, (size_t)nblocks * 32, hipMemcpyDeviceToHost);
+}
+extern "C" int gmk_debug_conv_trace_read_epi(unsigned long long* dst, int nblocks) {   // per block: 4 epilogue stamps (+4 unused)
+  if (!g_trace || nblocks > 65536) return -1;
+  return (int)hipMemcpy(dst, g_trace + 4ull * 65536, (size_t)nblocks * 64, hipMemcpyDeviceToHost);
+}
+#endif

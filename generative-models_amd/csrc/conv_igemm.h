@@ -30,6 +30,9 @@ struct ConvGeom {
   int act, epi;  // epi 0: +bias, act (and act' to dact_out); 1: * dact_in (dgrad)
   int seg_px, lg_seg_px, nseg;
   int PR, PC, PS, npos;
+#ifdef GMK_CONV_TRACE
+  unsigned long long* trace;   // tools-only build: per block {hw id, t_start, t_k_done, t_end} (wall_clock64 ticks)
+#endif
   int dbg;  // ablation bits for profiling builds (0 in production): 1 = no epilogue stores, 2 = no K loop, 4 = every chunk reloads chunk 0 (cache-resident operands, wrong results: the K loop without HBM latency)
 };
 
@@ -55,6 +58,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
   float* Xl = smem + 2 * MB * WS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef GMK_CONV_TRACE
+  const unsigned long long tr_t0 = wall_clock64();
+#endif
   const int wm = wave / WP, wp = wave % WP;
   const int h = lane >> 5, j = lane & 31;
   // Blocks go round-robin over the 8 XCDs (one L2 each; linear block id = x + y gridDim.x): XCD k takes the position
@@ -272,6 +278,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
     }
   }
 
+#ifdef GMK_CONV_TRACE
+  const unsigned long long tr_t1 = wall_clock64();
+#endif
   // ---- epilogue ----
   // Accumulator layout (rows = pixels, cols = channels): lane -> channel (lane & 31); register r -> pixel
   // (r & 3) + 8 (r >> 2) + 4 h of the wave's 32-pixel tile.  Stored like that every lane would write 16-byte
@@ -329,6 +338,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
         }
       }
       gmk_lds_barrier();
+#ifdef GMK_CONV_TRACE
+      if (g.trace && tid == 0 && py < 2 && i == 0) g.trace[4ull * 65536 + 8ull * (blockIdx.x + blockIdx.y * gridDim.x) + 2 * py] = wall_clock64();
+#endif
       // the activation switch is hoisted out of the store loop: GELU (the reference default) and identity
       // get straight-line code, the other activations share the generic switch
       auto store_rows = [&](auto actf) {
@@ -342,10 +354,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
           if (g.epi == 0) {
             const float bv = bvs[it];
             float4 a, d;
-            actf(v.x + bv, a.x, d.x);
-            actf(v.y + bv, a.y, d.y);
-            actf(v.z + bv, a.z, d.z);
-            actf(v.w + bv, a.w, d.w);
+            actf(make_float4(v.x + bv, v.y + bv, v.z + bv, v.w + bv), a, d);
             *(float4*)(g.y + idx) = a;
             if (g.dact_out) *(float4*)(g.dact_out + idx) = d;
           } else {
@@ -355,10 +364,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
           }
         }
       };
-      if (g.epi != 0) store_rows([](float z, float& a, float& d) { a = z; d = 1.f; });
+      if (g.epi != 0) store_rows([](const float4& z, float4& a, float4& d) { a = z; d = z; });   // (unused on the dgrad path)
       else GMK_WITH_ACT(g.act, store_rows)
+#ifdef GMK_CONV_TRACE
+      if (g.trace && tid == 0 && py < 2 && i == 0) g.trace[4ull * 65536 + 8ull * (blockIdx.x + blockIdx.y * gridDim.x) + 2 * py + 1] = wall_clock64();
+#endif
     }
   });
+#ifdef GMK_CONV_TRACE
+  if (g.trace && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the block's stores are acknowledged
+    const unsigned long long tr_t2 = wall_clock64();
+    const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
+    unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID, 32 bits
+    unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // XCC_ID[3:0]
+    unsigned long long* t = g.trace + 4ull * lin;
+    t[0] = ((unsigned long long)xcc << 32) | hw; t[1] = tr_t0; t[2] = tr_t1; t[3] = tr_t2;
+  }
+#endif
 }
 
 // Host-side launcher (one instantiation set per kernel size, defined in conv_igemm_k{3,5}.hip)
@@ -402,6 +425,10 @@ static int gmk_launch_conv_impl(ConvGeom& g, int mode, hipStream_t s) {
   if (lds > 160 * 1024) return GMK_E_SHAPE;
   dim3 grid((unsigned)((g.total_base + PT - 1) / PT), (unsigned)((g.M + MB - 1) / MB));
   const int nslot = (g.npos + 255) / 256;
+#ifdef GMK_CONV_TRACE
+  unsigned long long* gmk_conv_trace_buffer();
+  g.trace = gmk_conv_trace_buffer();
+#endif
 #define GMK_CONV_LAUNCH(MODE_, CK_, WM_, MT_)                                                              \
   do {                                                                                                     \
     auto kern = (nslot <= GMK_NS_LO(MODE_)) ? conv_igemm_kernel<MODE_, KS, CK_, WM_, MT_, GMK_NS_LO(MODE_)> \
@@ -426,3 +453,6 @@ static int gmk_launch_conv_impl(ConvGeom& g, int mode, hipStream_t s) {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? GMK_OK : (int)e;
 }
+#ifdef GMK_CONV_TRACE
+unsigned long long* gmk_conv_trace_buffer();   // conv_api.hip (tools-only build)
+#endif

@@ -137,17 +137,14 @@ __global__ __launch_bounds__(256) void conv_thin_in_kernel(const ConvGeom g) {
           *(float4*)(g.y + idx) = make_float4(z0 * d4.x, z1 * d4.y, z2 * d4.z, z3 * d4.w);
         } else {
           float4 a, d;
-          actf(z0, a.x, d.x);
-          actf(z1, a.y, d.y);
-          actf(z2, a.z, d.z);
-          actf(z3, a.w, d.w);
+          actf(make_float4(z0, z1, z2, z3), a, d);
           *(float4*)(g.y + idx) = a;
           if (g.dact_out) *(float4*)(g.dact_out + idx) = d;
         }
       }
     }
   };
-  if (DGRAD) run([](float z, float& a, float& d) { a = z; d = 1.f; });
+  if (DGRAD) run([](const float4& z, float4& a, float4& d) { a = z; d = z; });   // (unused on the dgrad path)
   else GMK_WITH_ACT(g.act, run)
 }
 

@@ -281,10 +281,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvGeom g) {
       if (g.epi == 0) {
         const float bv = bvs[it];
         float4 a, dd;
-        actf(v.x + bv, a.x, dd.x);
-        actf(v.y + bv, a.y, dd.y);
-        actf(v.z + bv, a.z, dd.z);
-        actf(v.w + bv, a.w, dd.w);
+        actf(make_float4(v.x + bv, v.y + bv, v.z + bv, v.w + bv), a, dd);
         *(float4*)(g.y + idxs[it]) = a;
         if (g.dact_out) *(float4*)(g.dact_out + idxs[it]) = dd;
       } else {
@@ -294,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvGeom g) {
       }
     }
   };
-  if (g.epi != 0) store_rows([](float z, float& a, float& d) { a = z; d = 1.f; });
+  if (g.epi != 0) store_rows([](const float4& z, float4& a, float4& d) { a = z; d = z; });   // (unused on the dgrad path)
   else GMK_WITH_ACT(g.act, store_rows)
 }
 

@@ -54,6 +54,37 @@ __device__ __forceinline__ void gmk_gelu_fwd(float z, float& a, float& d) {
   d = fmaf(z * 0.39894228040143267794f, e, cdf);
 }
 
+// The same GELU on two values at a time in packed fp32 (v_pk_mul_f32 / v_pk_fma_f32): 21 vector-ALU instructions per pair
+// instead of 38.  fp32 MFMA and the vector ALU share one issue port on gfx950 and a co-resident block in its K loop re-issues a
+// 64-cycle MFMA the moment the last one retires, so an overlapped epilogue advances roughly one instruction per MFMA
+// (tools/block_trace.py): its length is its instruction count.  Same operations in the same order as gmk_gelu_fwd: same bits.
+typedef float gmk_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gmk_gelu_fwd2(gmk_f2 z, gmk_f2& a, gmk_f2& d) {
+  const gmk_f2 ex = (z * z) * -0.72134752044448170368f;
+  gmk_f2 e, az, t, cs;
+  e.x = __builtin_amdgcn_exp2f(ex.x); e.y = __builtin_amdgcn_exp2f(ex.y);
+  az.x = fabsf(z.x); az.y = fabsf(z.y);
+  const gmk_f2 u = az * (0.3275911f * 0.70710678118654752440f) + 1.0f;
+  t.x = __builtin_amdgcn_rcpf(u.x); t.y = __builtin_amdgcn_rcpf(u.y);
+  gmk_f2 p = t * (0.5f * 1.061405429f) + (0.5f * -1.453152027f);
+  p = p * t + (0.5f * 1.421413741f);
+  p = p * t + (0.5f * -0.284496736f);
+  p = p * t + (0.5f * 0.254829592f);
+  const gmk_f2 q = p * t * e;
+  const gmk_f2 hq = 0.5f - q;
+  cs.x = copysignf(hq.x, z.x); cs.y = copysignf(hq.y, z.y);
+  const gmk_f2 cdf = 0.5f + cs;
+  a = z * cdf;
+  d = (z * 0.39894228040143267794f) * e + cdf;
+}
+__device__ __forceinline__ void gmk_gelu_fwd4(const float4& z, float4& a, float4& d) {
+  gmk_f2 a0, d0, a1, d1;
+  gmk_gelu_fwd2(gmk_f2{z.x, z.y}, a0, d0);
+  gmk_gelu_fwd2(gmk_f2{z.z, z.w}, a1, d1);
+  a = make_float4(a0.x, a0.y, a1.x, a1.y);
+  d = make_float4(d0.x, d0.y, d1.x, d1.y);
+}
+
 __device__ __forceinline__ void gmk_act_fwd(int act, float z, float& a, float& d) {
   switch (act) {
     case GMK_ACT_RELU:
@@ -106,15 +137,20 @@ __device__ __forceinline__ void gmk_act_fwd(int act, float z, float& a, float& d
   }
 }
 
-// Epilogue helper: run `body(actf)` with actf(z, a, d) specialised for the (block-uniform) activation `act`: identity,
-// GELU (the reference default) and ReLU get straight-line code, the rest share the per-element switch (specialising all
-// seven triples the build time of the conv kernels for activations nobody benchmarks).
+// Epilogue helper: run `body(actf)` with actf(float4 z, float4& a, float4& d) specialised for the (block-uniform) activation
+// `act`: identity, GELU (the reference default; packed fp32) and ReLU get straight-line code, the rest share the per-element
+// switch (specialising all seven triples the build time of the conv kernels for activations nobody benchmarks).
+#define GMK_ACT4_SCALAR(expr_)                                                                      \
+  [=](const float4& z_, float4& a_, float4& d_) {                                                   \
+    auto f1_ = [=](float zz_, float& aa_, float& dd_) { expr_; };                                   \
+    f1_(z_.x, a_.x, d_.x); f1_(z_.y, a_.y, d_.y); f1_(z_.z, a_.z, d_.z); f1_(z_.w, a_.w, d_.w);     \
+  }
 #define GMK_WITH_ACT(act, body)                                                                            \
   switch (act) {                                                                                           \
-    case GMK_ACT_GELU: body([](float z_, float& a_, float& d_) { gmk_gelu_fwd(z_, a_, d_); }); break;      \
-    case GMK_ACT_RELU: body([](float z_, float& a_, float& d_) { gmk_act_fwd(GMK_ACT_RELU, z_, a_, d_); }); break; \
-    case GMK_ACT_NONE: body([](float z_, float& a_, float& d_) { a_ = z_; d_ = 1.f; }); break;             \
-    default: { const int act__ = (act); body([act__](float z_, float& a_, float& d_) { gmk_act_fwd(act__, z_, a_, d_); }); } break; \
+    case GMK_ACT_GELU: body([](const float4& z_, float4& a_, float4& d_) { gmk_gelu_fwd4(z_, a_, d_); }); break; \
+    case GMK_ACT_RELU: body(GMK_ACT4_SCALAR(gmk_act_fwd(GMK_ACT_RELU, zz_, aa_, dd_))); break;             \
+    case GMK_ACT_NONE: body([](const float4& z_, float4& a_, float4& d_) { a_ = z_; d_ = make_float4(1.f, 1.f, 1.f, 1.f); }); break; \
+    default: { const int act__ = (act); body(GMK_ACT4_SCALAR(gmk_act_fwd(act__, zz_, aa_, dd_))); } break; \
   }
 
 // ---- buffer (SRD) loads: hardware bounds check returns 0 for out-of-range offsets, so padded /
