@@ -2,7 +2,7 @@
 
 The two vector-ALU kernels of the 3-channel-side layers (csrc/conv_thin_in.hip, conv_thin_outv.hip) are 5-6 us faster per
 launch than the matrix-core kernels they replace on every device measured, yet the train step around them gets 2.8 %
-faster on most devices of the pool and 1.5-3.5 % slower on some (DESIGN.md section 7).  `tune_thin_paths` times a
+faster on most devices of the pool and 1.5-3.5 % slower on some (DESIGN.md section 5).  `tune_thin_paths` times a
 caller-supplied step with the paths off and on, in interleaved windows on this device, and keeps the faster setting
 (gmk_conv_set_thin_paths, include/gmk.h).  No counterpart in the reference.
 

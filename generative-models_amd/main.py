@@ -170,6 +170,9 @@ def main(args):
         # kernel-path choice for this device on a throw-away replica and synthetic input (gmk/tune.py): the real
         # parameters, the optimizer state and the data order are untouched
         from gmk.tune import tune_thin_paths
+        # the replica's init and its eps draws go through torch's global generators: put them back afterwards, so that a tuned
+        # run draws the same eps / shuffles as an untuned one
+        rng_cpu, rng_dev = torch.get_rng_state(), torch.cuda.get_rng_state(device)
         t_model = Autoencoder(variational=args.variational, latent_size=args.latent_size, num_channels=args.num_channels,
                               kernel_size=args.kernel_size, act=args.act_fn, sigmoid=args.sigmoid,
                               interpolation=args.interpolation, no_pool=args.no_pool, no_upsample=args.no_upsample,
@@ -185,6 +188,8 @@ def main(args):
         if rank == 0:
             print(f'\n\nKernel paths on this device (thin_in, thin_outv): {tuned["choice"]}  {tuned["ms"]}')
         del t_model, t_optim, t_image, t_step
+        torch.set_rng_state(rng_cpu)
+        torch.cuda.set_rng_state(rng_dev, device)
     optim = FusedAdamW(model.parameters(), lr=args.lr, weight_decay=args.wd)
     lr_scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optim, T_max=args.epochs * len(train_dataloader))
     reducer = GradReducer(model, optim) if world > 1 else None
