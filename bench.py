@@ -301,7 +301,9 @@ def main():
     model, optim, sched = build(device)
     if world > 1:  # identical replicas: broadcast rank 0's parameters
         broadcast_(optim.flat_param, src=0)
-    reducer = GradReducer(model, optim)
+    # GMK_DP_REHEARSE=1 (tools/README.md): one rank, the whole DP machinery (RCCL all-reduce per bucket, segment-wise replay)
+    # under the timed step -- what data parallelism costs a rank before any xGMI traffic.  Not a bench configuration.
+    reducer = GradReducer(model, optim, force=os.environ.get("GMK_DP_REHEARSE", "0") == "1")
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     batches = [torch.rand(PER_GPU_BATCH, 3, 32, 32, device=device, generator=gen) for _ in range(4)]
     egen = torch.Generator(device=device).manual_seed(4321 + rank)
@@ -352,6 +354,8 @@ def main():
                              "ms_per_step_by_choice": tuned["ms"]},
             "step_mfma_frac": round(ips / world * TRAIN_MFLOP_PER_IMG * 1e6 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
         }
+        if reducer.active and world == 1:
+            out["dp_rehearsal"] = "one rank, every gradient bucket through an RCCL all-reduce (GMK_DP_REHEARSE=1)"
         out["roofline"] = dominant_kernel_roofline(device)
         out["roofline_igemm_s2"] = igemm_s2_kernel_roofline(device)
         out["roofline_wino"] = wino_kernel_roofline(device)
@@ -373,6 +377,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -40,9 +40,13 @@ def broadcast_(t, src=0, group=None):
 
 
 class GradReducer:
-    def __init__(self, model, optimizer, process_group=None):
+    def __init__(self, model, optimizer, process_group=None, force=False):
+        """`force`: run the bucketed all-reduce path even in a one-rank group (a sum over one rank is the identity).  A
+        one-GPU box can then put the REAL transport -- RCCL's own stream, its event edges to the step's streams, the
+        segment-wise replay of the launch plan -- under the step (tests/test_dp_equiv_gpu.py); never set in production."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (bool(force) and dist.is_initialized())
         self.opt = optimizer
         enc_fc = [model.encoder.fc.weight, model.encoder.fc.bias]
         enc_conv = [p for n, p in model.encoder.named_parameters() if not n.startswith("fc.")]
@@ -58,7 +62,7 @@ class GradReducer:
 
     def ready(self, name):
         """Called by train_step when the gradients of bucket `name` have been enqueued."""
-        if self.world == 1:
+        if not self.active:
             return
         a, b = self.buckets[name]
         if self._async:
@@ -81,17 +85,52 @@ class GradReducer:
         self._by_name = {}
 
 
+MIN_HW_QUEUES_DP = 8
+
+
+def ensure_hw_queues(n=MIN_HW_QUEUES_DP):
+    """Raises GPU_MAX_HW_QUEUES (HIP's hardware queues per process, default 4) to `n` for a data-parallel rank.  Must run
+    before the process's first HIP call (torch.cuda.is_available() is one): the runtime reads it once.
+
+    Why: the step runs on three streams (dgrad chain + two weight-gradient streams, gmk.ops.SideQueue) and HIP maps streams
+    onto its hardware queues round-robin.  RCCL takes queues of its own when the group is created; with 4 in all, one
+    weight-gradient stream lands on the MAIN stream's hardware queue and its kernels serialise with the dgrad chain.
+    Measured on one MI355X with a one-rank RCCL group under the step (tools/rehearse/rccl_world1.sh): 1.173 ms per step
+    with 4 queues, 1.050 ms with 8, 1.000 ms without the group."""
+    import os
+    try:
+        cur = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        cur = 4
+    if cur < n:
+        if torch.cuda.is_initialized():
+            import warnings
+            warnings.warn("gmk.parallel: the HIP runtime is already initialised, GPU_MAX_HW_QUEUES=%d stays; export "
+                          "GPU_MAX_HW_QUEUES=%d before starting a data-parallel rank" % (cur, n))
+            return cur
+        os.environ["GPU_MAX_HW_QUEUES"] = str(n)
+        return n
+    return cur
+
+
 def init_from_env():
     """One process per GPU; reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun contract)."""
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 or os.environ.get("GMK_DP_REHEARSE", "0") == "1":
+        ensure_hw_queues()
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # Rehearsal knobs (a 1-GPU box cannot run RCCL between two ranks): GMK_DIST_BACKEND=gloo + GMK_FORCE_DEVICE=0 put
     # every rank on one card and exchange device tensors over gloo; the code path above the transport is the same.
     if os.environ.get("GMK_FORCE_DEVICE") is not None:
         local = int(os.environ["GMK_FORCE_DEVICE"])
-    if world > 1 and not dist.is_initialized():
+    # GMK_DP_REHEARSE=1: a group even for ONE rank, so that GradReducer(force=True) puts RCCL under the step on a one-GPU box
+    rehearse = os.environ.get("GMK_DP_REHEARSE", "0") == "1"
+    if rehearse:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if (world > 1 or rehearse) and not dist.is_initialized():
         backend = os.environ.get("GMK_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available() and backend == "nccl":
             torch.cuda.set_device(local)

@@ -336,7 +336,7 @@ class Autoencoder(nn.Module):
             eps = None
         main_stream = torch.cuda.current_stream(image.device)
         self._step_tensors()
-        dp = reducer is not None and reducer.world > 1
+        dp = reducer is not None and reducer.active
         side = ops.side_queue(image.device)
         early = self._early_ctx(optimizer, side, image.device, main_stream)
         key = (tuple(image.shape), float(beta), bool(mse_prior), main_stream.cuda_stream, dp, self._step_cache[3],
@@ -381,7 +381,7 @@ class Autoencoder(nn.Module):
     def _bucket_ready(name, reducer, side, early=None):
         """Gradient bucket `name` is enqueued: start its all-reduce behind the weight-gradient streams and, with `early`,
         its AdamW update behind that."""
-        if reducer is not None and reducer.world > 1:
+        if reducer is not None and reducer.active:
             if side is None:
                 reducer.ready(name)
             else:  # the bucket's gradients are ordered on the side stream(s): the all-reduce waits for them

@@ -6,10 +6,16 @@ import torch
 import bench
 dev = torch.device("cuda:0")
 model, optim, sched = bench.build(dev)
+red = None
+if os.environ.get("GMK_DP_REHEARSE", "0") == "1":   # one-rank RCCL group under the step (gmk/parallel.py)
+    from gmk.parallel import init_from_env, GradReducer
+    init_from_env()
+    red = GradReducer(model, optim, force=True)
 x = torch.rand(256, 3, 32, 32, device=dev)
 eps = torch.randn(256, 256, device=dev)
 def step():
-    l = model.train_step(x, beta=5e-6, eps=eps, optimizer=optim if os.environ.get("GMK_EARLY_ADAMW", "0") != "0" else None)
+    l = model.train_step(x, beta=5e-6, eps=eps, reducer=red, optimizer=optim if os.environ.get("GMK_EARLY_ADAMW", "0") != "0" else None)
+    if red is not None: red.wait()
     optim.step(); sched.step()
 for _ in range(20): step()
 torch.cuda.synchronize()
