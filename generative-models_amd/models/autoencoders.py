@@ -382,12 +382,16 @@ class Autoencoder(nn.Module):
         """Gradient bucket `name` is enqueued: start its all-reduce behind the weight-gradient streams and, with `early`,
         its AdamW update behind that."""
         if reducer is not None and reducer.active:
+            merged = early is None
             if side is None:
-                reducer.ready(name)
-            else:  # the bucket's gradients are ordered on the side stream(s): the all-reduce waits for them
+                reducer.ready(name, merged)
+            elif not (merged and name == "decoder"):
+                # the bucket's gradients are ordered on the weight-gradient streams: the all-reduce is issued behind them.
+                # (Issued from a stream of its own that waits for both -- so that neither waits for the other's backlog --
+                # the step took 1.73 ms instead of 1.01: a queue whose head is a long-pending wait slows every dispatch.)
                 side.gather()
                 with torch.cuda.stream(side.stream):
-                    reducer.ready(name)
+                    reducer.ready(name, merged)
         if early is not None and name != "encoder.conv":
             optimizer, seg, opt_stream, main_stream = early
             # the update must follow the bucket's weight gradients (side stream), the kernels that read its weights
