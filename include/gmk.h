@@ -58,7 +58,11 @@ enum gmk_act {
 int gmk_version(void);
 /* gmk_stream_wait_stream: everything enqueued on `waiter` after this call runs behind everything enqueued on `on`
  *   before it (hipEventRecord + hipStreamWaitEvent on an event of a ring of 64 per device, created on first use; the ring
- *   is that of the device that owns `on`, whatever the current device).
+ *   is that of the device that owns `on`, whatever the current device).  The events carry hipEventDisableSystemFence:
+ *   they order streams of ONE device, whose kernels bring their own agent-scope acquire / release; they do NOT make device
+ *   memory visible to the host or to another device (a default record does, by writing the L2s back and invalidating them:
+ *   3 % of the train step at 25 forks and joins).  A host read or a peer access after such a wait needs a fence of its own:
+ *   any stream / device synchronisation or copy of the HIP runtime, an ordinary event.
  *   No counterpart in the reference: host plumbing of the backward pass's second stream (weight gradients), which
  *   autograd's single stream does not have (main.py:51). */
 int gmk_stream_wait_stream(gmk_stream_t waiter, gmk_stream_t on);

@@ -37,7 +37,10 @@ print("reps", reps, "WG16", os.environ.get("GMK_WG16", "1"), "SIDE", os.environ.
 # ---- whole runs: K optimizer steps from the same initial state, twice; final parameters compared bit for bit
 K = int(os.environ.get("DET_STEPS", "40"))
 finals = []
-for run in range(2):
+for run in range(3):
+    if run == 2:   # the same run on ONE stream, launch by launch: no fork / join event anywhere
+        os.environ["GMK_SIDE_WGRAD"] = "0"
+        os.environ["GMK_STEP_PLAN"] = "0"
     torch.manual_seed(0)
     model, optim, sched = build(dev)
     gen = torch.Generator(device=dev).manual_seed(1234)
@@ -53,5 +56,8 @@ for run in range(2):
     torch.cuda.synchronize()
     finals.append((optim.flat_param.clone(), losses.clone()))
 same = torch.equal(finals[0][0], finals[1][0])
+same1 = torch.equal(finals[0][0], finals[2][0])
+print("three streams + launch plan against one stream, launch by launch,", K, "steps:",
+      "bit-identical" if same1 else f"DIFFER (max abs {float((finals[0][0] - finals[2][0]).abs().max()):.3e})")
 print("runs of", K, "steps:", "bit-identical" if same else f"DIFFER (max abs {float((finals[0][0] - finals[1][0]).abs().max()):.3e})",
       "losses", finals[0][1].tolist(), finals[1][1].tolist())
