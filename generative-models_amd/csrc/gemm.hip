@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const GemmArgs g) {
   // without a branch around any load.
   constexpr int GPD = 4;
   float4 arr[GPD][2], brr[GPD][2];
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto zero_unless = [](bool ok, const float4& v) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); };
   auto load_chunk_to = [&](int k0, float4* ar, float4* br) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -210,10 +210,12 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const GemmArgs g) {
     float* Bs = smem[buf][1];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const float4 a = (a_ok[u] && k0 + a_k[u] < kend) ? ar[u] : z4;
+      // component-wise selects: written as `cond ? ar[u] : z4` the <false, false> instantiation selected between the
+      // ADDRESSES of the two (z4 parked in scratch) and read the winner back with a flat load inside the K loop
+      const float4 a = zero_unless(a_ok[u] && k0 + a_k[u] < kend, ar[u]);
       if (a_kfast) { float* d = As + a_l[u]; d[0] = a.x; d[GLD] = a.y; d[2 * GLD] = a.z; d[3 * GLD] = a.w; }
       else *(float4*)(As + a_l[u]) = a;
-      const float4 b = (b_ok[u] && k0 + b_k[u] < kend) ? br[u] : z4;
+      const float4 b = zero_unless(b_ok[u] && k0 + b_k[u] < kend, br[u]);
       if (b_kfast) { float* d = Bs + b_l[u]; d[0] = b.x; d[GLD] = b.y; d[2 * GLD] = b.z; d[3 * GLD] = b.w; }
       else *(float4*)(Bs + b_l[u]) = b;
     }
