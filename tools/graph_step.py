@@ -17,9 +17,10 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 device = torch.device("cuda:0")
 model, optim, sched = bench.build(device)
 gen = torch.Generator(device=device).manual_seed(1234)
-batch = torch.rand(256, 3, 32, 32, device=device, generator=gen)
+B = int(os.environ.get("KB_BATCH", "256"))
+batch = torch.rand(B, 3, 32, 32, device=device, generator=gen)
 egen = torch.Generator(device=device).manual_seed(4321)
-eps = torch.randn(256, 256, device=device, generator=egen)
+eps = torch.randn(B, 256, device=device, generator=egen)
 beta = 5e-6
 
 
