@@ -15,7 +15,7 @@
  *     per-device kernel-path selection of gmk_conv_set_thin_paths (one atomic word per device); (2) per-device caches that
  *     only ever grow (event ring of gmk_stream_wait_stream, raised dynamic-LDS limits, the address of the static scratch of
  *     gmk_vae_loss_fwd_bwd_static); (3) the calling thread's plan being recorded between gmk_plan_begin / gmk_plan_end;
- *     (4) profiling knobs read once from the environment (GMK_WINO, GMK_*_DBG: ablation builds, 0 in production);
+ *     (4) profiling knobs read once from the environment (GMK_WINO, GMK_EVENT_SCOPE, GMK_*_DBG: ablation builds, 0 in production);
  *   - return 0 on success, a negative GMK_E_* on a rejected argument, a positive hipError_t if a
  *     launch failed; gmk_strerror() names either.
  *   - spatial sizes must be powers of two (the reference fixes 32x32; 64x64 for config 5).
