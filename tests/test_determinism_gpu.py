@@ -167,3 +167,38 @@ def test_deferred_batch_reduce_is_bit_identical_to_per_layer_reduces(monkeypatch
     for (ga, la), (gb, lb) in zip(*res):
         assert torch.equal(la, lb)
         assert torch.equal(ga, gb), float((ga - gb).abs().max())
+
+
+@pytest.mark.parametrize("numel", [1 << 16, 1 << 24])
+def test_fence_less_fork_events_order_two_streams_of_one_device(numel):
+    """gmk_stream_wait_stream's events carry hipEventDisableSystemFence (include/gmk.h): what a kernel wrote on one stream must
+    still be what the next kernel reads on the other -- a chain of 200 dependent launches ping-ponging between two streams
+    (256 KB tensors that live in the L2s of the XCDs that wrote them, and 64 MB ones that do not) equals the same chain on
+    one stream, bit for bit."""
+    from gmk import ops
+    from gmk._lib import lib, check
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(3)
+    x0 = torch.rand(numel, device=dev, generator=g) + 0.5
+    cs = [torch.rand(numel, device=dev, generator=g) * 0.02 + 0.99 for _ in range(4)]
+    ref = x0
+    for k in range(200):
+        ref = ops.ew_mul(ref, cs[k % 4])
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    main = torch.cuda.current_stream(dev)
+    keep = [x0]
+    x = x0
+    check(lib().gmk_stream_wait_stream(sa.cuda_stream, main.cuda_stream))
+    for k in range(200):
+        s, o = (sa, sb) if k % 2 == 0 else (sb, sa)
+        if k:
+            check(lib().gmk_stream_wait_stream(s.cuda_stream, o.cuda_stream))
+        with torch.cuda.stream(s), ops.stream_scope(s):
+            x = ops.ew_mul(x, cs[k % 4])
+        keep.append(x)
+    check(lib().gmk_stream_wait_stream(main.cuda_stream, sb.cuda_stream))
+    check(lib().gmk_stream_wait_stream(main.cuda_stream, sa.cuda_stream))
+    out = x.clone()          # main stream, behind both
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)

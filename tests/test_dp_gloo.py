@@ -42,13 +42,25 @@ def _worker(rank, world, port, q):
         # every per-parameter .grad sees the flat data
         first = next(m.parameters())
         assert torch.equal(first.grad.reshape(-1), opt.flat_grad[:first.numel()])
-        for name in ("decoder", "encoder.fc", "encoder.conv"):
-            red.ready(name)
+        # decoder + encoder.fc travel as ONE all-reduce issued at ready("encoder.fc"): ready("decoder") alone moves nothing
+        red.ready("decoder")
+        assert torch.equal(opt.flat_grad, local)
+        red.ready("encoder.fc")
+        a, b = red._fc_dec
+        assert (a, b) == (red.buckets["encoder.fc"][0], red.buckets["decoder"][1])
+        ca, cb = red.buckets["encoder.conv"]
+        assert torch.equal(opt.flat_grad[ca:cb], local[ca:cb]) and not torch.equal(opt.flat_grad[a:b], local[a:b])
+        red.ready("encoder.conv")
         red.wait()
         both = [torch.randn(opt._numel, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
         expect = sum(both)
         assert torch.allclose(opt.flat_grad, expect, atol=1e-6)
         assert abs(opt.grad_scale - 1.0 / world) < 1e-12          # the mean is folded into AdamW
+        opt.flat_grad.copy_(local)                                  # merged=False (bucket-wise early AdamW): three collectives, same sums
+        for name in ("decoder", "encoder.fc", "encoder.conv"):
+            red.ready(name, merged=False)
+        red.wait()
+        assert torch.allclose(opt.flat_grad, expect, atol=1e-6)
         # FID / IS exchange steps: the PRODUCT host path (metrics.feature_moments / _logit_stats with sharded=True), with
         # the two HIP kernels replaced by CPU stand-ins of their documented contract (include/gmk.h) -- no GPU here
         import metrics
