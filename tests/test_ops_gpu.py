@@ -183,7 +183,9 @@ def test_deconv2d_all(shape):
     close(db, gb, name="db")
 
 
-LIN_SHAPES = [(8, 4096, 512), (8, 256, 4096), (256, 4096, 512), (256, 256, 4096), (5, 100, 37), (50, 4096, 256)]
+LIN_SHAPES = [(8, 4096, 512), (8, 256, 4096), (256, 4096, 512), (256, 256, 4096), (5, 100, 37), (50, 4096, 256),
+              # configs[4]'s FC layers (deep-K split forward, 1024- and 4096-tile grids) and a ragged shape of that size
+              (256, 16384, 1024), (256, 512, 16384), (260, 8200, 1028)]
 
 
 @pytest.mark.parametrize("shape", LIN_SHAPES)
@@ -289,7 +291,7 @@ def test_upsample2(mode, shape):
 
 
 # ---------------------------------------------------------------------------------------------- fused VAE tail
-@pytest.mark.parametrize("shape", [(256, 4096, 256), (8, 4096, 256), (50, 1024, 32), (4, 64, 8), (300, 96, 20)])
+@pytest.mark.parametrize("shape", [(256, 4096, 256), (8, 4096, 256), (50, 1024, 32), (4, 64, 8), (300, 96, 20), (256, 16384, 512)])
 def test_linear_reparam_head_and_tail(shape):
     """gmk_linear_fwd_reparam / gmk_linear_dgrad_reparam (encoder head + reparameterisation, decoder fc dgrad +
     reparameterisation backward + beta*KL gradient, /root/reference/models/autoencoders.py:57-61,169-176 and
