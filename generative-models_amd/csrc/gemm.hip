@@ -5,6 +5,7 @@
 // Small-M shapes (M = batch) are split along K into fp32 slabs and reduced in a fixed order.
 #include "gmk_common.h"
 #include "plan.h"
+#include <stdlib.h>
 
 #define GT 64
 #define GK 32
@@ -290,6 +291,154 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const GemmArgs g) {
   }
 }
 
+// ---- the same kernel with a K loop free of VALU work (round 3) -------------------------------------------------------
+// PMC of gemm_f32_pipe_kernel at the configs[4] FC shapes: 5-7 VALU instructions per MFMA (per-chunk 64-bit address
+// arithmetic, end-of-K clamps, zero selects), and fp32 MFMA shares the VALU issue port: matrix pipe 44-58 % busy whatever
+// the tile shape.  Here every per-lane address is a 32-bit byte offset computed ONCE and the chunk's position is a uniform
+// base pointer (global_load ... saddr form: no vector instruction per load); nothing is clamped or zeroed per lane:
+//   - rows / columns of a ragged edge tile re-read a valid row: they only reach accumulator rows / columns that are
+//     never written (an MFMA row depends on its own A row only);
+//   - the K range of every block is a whole number of chunks (host: K % 32 == 0), chunks of the prefetch ring past the
+//     end re-read the last chunk and are never multiplied (uniform guard around the MFMA section).
+// Same chunk order and accumulation order as gemm_f32_pipe_kernel: bit-identical results.
+template <bool a_kfast, bool b_kfast>
+__global__ __launch_bounds__(256) void gemm_f32_lean_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float smem[2][2][GK * GLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ncs = g.cs_src ? (g.cs_N + 63) / 64 : 0;
+  int bid = blockIdx.x;
+  if (bid < ncs) {   // block-uniform branch
+    gemm_colsum_block(g, bid, &smem[0][0][0]);
+    return;
+  }
+  bid -= ncs;
+  const int ntx = (g.N + GT - 1) / GT, nty = (g.M + GT - 1) / GT;
+  const int bx = bid % ntx, by = (bid / ntx) % nty, bz = bid / (ntx * nty);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int i0 = by * GT, j0 = bx * GT;
+  const int kbeg = bz * g.kper;
+  const int kend = min(g.K, kbeg + g.kper);
+  const int nch = (kend - kbeg) / GK;   // whole chunks (host guarantees it)
+  // per-lane byte offsets from the chunk's uniform base, LDS offsets of the quads
+  unsigned a_bo[2], b_bo[2];
+  int a_l[2], b_l[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (a_kfast) {
+      const int r = tid / 8 + 32 * u, kq = tid % 8;
+      const int gi = min(i0 + r, g.M - 1);
+      a_bo[u] = (unsigned)(((long long)gi * g.sai + kq * 4) * 4);
+      a_l[u] = kq * 4 * GLD + r;
+    } else {
+      const int k = tid / 16 + 16 * u, q = tid % 16;
+      const int gi = min(i0 + q * 4, g.M - 4);
+      a_bo[u] = (unsigned)(((long long)k * g.sak + gi) * 4);
+      a_l[u] = k * GLD + q * 4;
+    }
+    if (b_kfast) {
+      const int r = tid / 8 + 32 * u, kq = tid % 8;
+      const int gj = min(j0 + r, g.N - 1);
+      b_bo[u] = (unsigned)(((long long)gj * g.sbj + kq * 4) * 4);
+      b_l[u] = kq * 4 * GLD + r;
+    } else {
+      const int k = tid / 16 + 16 * u, q = tid % 16;
+      const int gj = min(j0 + q * 4, g.N - 4);
+      b_bo[u] = (unsigned)(((long long)k * g.sbk + gj) * 4);
+      b_l[u] = k * GLD + q * 4;
+    }
+  }
+  constexpr int GPD = 4;
+  float4 arr[GPD][2], brr[GPD][2];
+  const int klast = kend - GK;
+  auto load_chunk_to = [&](int k0, float4* ar, float4* br) {
+    const int kc = k0 < klast ? k0 : klast;   // uniform
+    const char* ca = (const char*)(g.A + (a_kfast ? (long long)kc : (long long)kc * g.sak));
+    const char* cb = (const char*)(g.B + (b_kfast ? (long long)kc : (long long)kc * g.sbk));
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      ar[u] = *(const float4*)(ca + a_bo[u]);
+      br[u] = *(const float4*)(cb + b_bo[u]);
+    }
+  };
+  auto store_chunk_from = [&](int buf, const float4* ar, const float4* br) {
+    float* As = smem[buf][0];
+    float* Bs = smem[buf][1];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float4 a = ar[u];
+      if (a_kfast) { float* d = As + a_l[u]; d[0] = a.x; d[GLD] = a.y; d[2 * GLD] = a.z; d[3 * GLD] = a.w; }
+      else *(float4*)(As + a_l[u]) = a;
+      const float4 b = br[u];
+      if (b_kfast) { float* d = Bs + b_l[u]; d[0] = b.x; d[GLD] = b.y; d[2 * GLD] = b.z; d[3 * GLD] = b.w; }
+      else *(float4*)(Bs + b_l[u]) = b;
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  auto mfma_chunk = [&](int buf) {
+    const float* As = smem[buf][0];
+    const float* Bs = smem[buf][1];
+#pragma unroll
+    for (int s = 0; s < GK / 2; ++s) {
+      const float a = As[(2 * s + h) * GLD + wr * 32 + l31];
+      const float b = Bs[(2 * s + h) * GLD + wc * 32 + l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < GPD; ++u) load_chunk_to(kbeg + u * GK, arr[u], brr[u]);
+  store_chunk_from(0, arr[0], brr[0]);
+  load_chunk_to(kbeg + GPD * GK, arr[0], brr[0]);
+  for (int i = 0; i < nch; i += GPD) {
+#pragma unroll
+    for (int u = 0; u < GPD; ++u) {
+      gmk_lds_barrier();
+      if (i + u < nch) mfma_chunk(u & 1);   // uniform
+      store_chunk_from((u + 1) & 1, arr[(u + 1) % GPD], brr[(u + 1) % GPD]);
+      load_chunk_to(kbeg + (i + u + 1 + GPD) * GK, arr[(u + 1) % GPD], brr[(u + 1) % GPD]);
+    }
+  }
+  const int j = j0 + wc * 32 + l31;
+  if (j >= g.N) return;
+  if (g.slab) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (i < g.M) g.slab[((size_t)bz * g.M + i) * g.N + j] = acc[r];
+    }
+    return;
+  }
+  float mulv[16];
+  const float bv = (g.epi == GEPI_BIAS_ACT && g.bias) ? g.bias[j] : 0.f;
+  if (g.epi == GEPI_MUL && g.mul) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int ic = i < g.M ? i : g.M - 1;
+      mulv[r] = g.mul[(size_t)ic * g.ldc + j];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mulv[r] = 1.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (i >= g.M) continue;
+    const size_t idx = (size_t)i * g.ldc + j;
+    if (g.epi == GEPI_BIAS_ACT) {
+      float a, d;
+      gmk_act_fwd(g.act, acc[r] + bv, a, d);
+      g.C[idx] = a;
+      if (g.dact) g.dact[idx] = d;
+    } else {
+      g.C[idx] = acc[r] * mulv[r];
+    }
+  }
+}
+
 // Reparameterisation (/root/reference/models/autoencoders.py:169-176) in the epilogue of the encoder fc's split-K
 // reduction: a thread sums the adjacent columns (2l, 2l+1) = (mu, log_var), writes them to `stats` and
 // z = mu + exp(log_var / 2) * eps next to them.
@@ -414,9 +563,20 @@ static int run_gemm(GemmArgs g, void* ws, size_t ws_bytes, hipStream_t s) {
   const bool a_fast = a_k ? (g.K % 4 == 0 && g.sai % 4 == 0) : (g.sai == 1 && g.M % 4 == 0 && g.sak % 4 == 0);
   const bool b_fast = b_k ? (g.K % 4 == 0 && g.sbj % 4 == 0) : (g.sbj == 1 && g.N % 4 == 0 && g.sbk % 4 == 0);
   bool cs_done = false;
+  // the VALU-free K loop wants whole chunks, at least 4 rows / columns, and operands whose byte offsets fit 32 bits
+  static const bool lean_off = [] { const char* e = getenv("GMK_GEMM_LEAN"); return e && e[0] == '0'; }();   // A/B knob
+  const long long a_span = a_k ? (long long)g.M * g.sai : (long long)GK * g.sak + g.M;
+  const long long b_span = b_k ? (long long)g.N * g.sbj : (long long)GK * g.sbk + g.N;
+  const bool lean = !lean_off && g.K % GK == 0 && g.M >= 4 && g.N >= 4 && a_span < (1LL << 29) && b_span < (1LL << 29);
   if (a_fast && b_fast && gmk_aligned16(g.A) && gmk_aligned16(g.B) && g.K >= 4) {
     dim3 grid1(grid.x * grid.y * grid.z);
     if (want_cs) { grid1.x += (g.cs_N + 63) / 64; cs_done = true; }   // column-sum blocks ride in the same launch, first
+    if (lean) {
+      if (a_k && b_k) hipLaunchKernelGGL((gemm_f32_lean_kernel<true, true>), grid1, dim3(256), 0, s, g);
+      else if (a_k) hipLaunchKernelGGL((gemm_f32_lean_kernel<true, false>), grid1, dim3(256), 0, s, g);
+      else if (b_k) hipLaunchKernelGGL((gemm_f32_lean_kernel<false, true>), grid1, dim3(256), 0, s, g);
+      else hipLaunchKernelGGL((gemm_f32_lean_kernel<false, false>), grid1, dim3(256), 0, s, g);
+    } else
     if (a_k && b_k) hipLaunchKernelGGL((gemm_f32_pipe_kernel<true, true>), grid1, dim3(256), 0, s, g);
     else if (a_k) hipLaunchKernelGGL((gemm_f32_pipe_kernel<true, false>), grid1, dim3(256), 0, s, g);
     else if (b_k) hipLaunchKernelGGL((gemm_f32_pipe_kernel<false, true>), grid1, dim3(256), 0, s, g);
