@@ -26,6 +26,7 @@ struct GemmArgs {
   int ldc, epi, act;
   int kper;      // K range per split
   float* slab;   // != nullptr: write raw partials slab[z][M][N]
+  int remap;     // lean kernel: XCD-aware tile order
 };
 
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, int i, int j, float v) {
@@ -312,8 +313,16 @@ __global__ __launch_bounds__(256) void gemm_f32_lean_kernel(const GemmArgs g) {
     return;
   }
   bid -= ncs;
-  const int ntx = (g.N + GT - 1) / GT, nty = (g.M + GT - 1) / GT;
-  const int bx = bid % ntx, by = (bid / ntx) % nty, bz = bid / (ntx * nty);
+  const int ntx = (g.N + GT - 1) / GT, nty = (g.M + GT - 1) / GT, ntile = ntx * nty;
+  // Tile order: blocks go round-robin over the 8 XCDs (one L2 each), so XCD k takes the contiguous tile range
+  // [k ntile/8, (k+1) ntile/8) of its K split, and inside it the dimension with FEWER tiles runs fastest: the blocks that
+  // share the big operand's tile (the weight tile of an M = 256 layer: 4 row tiles) run back to back on one L2 (PMC at
+  // configs[4]'s enc.fc dgrad before: 223 MB read from HBM for 67 MB of weights).
+  const int bz = bid / ntile;
+  int t = bid - bz * ntile;
+  if (g.remap && (ntile & 7) == 0) t = (t & 7) * (ntile >> 3) + (t >> 3);
+  int bx, by;
+  if (g.remap && nty <= ntx) { by = t % nty; bx = t / nty; } else { bx = t % ntx; by = t / ntx; }
   const int wr = wave >> 1, wc = wave & 1;
   const int h = lane >> 5, l31 = lane & 31;
   const int i0 = by * GT, j0 = bx * GT;
@@ -572,6 +581,8 @@ static int run_gemm(GemmArgs g, void* ws, size_t ws_bytes, hipStream_t s) {
     dim3 grid1(grid.x * grid.y * grid.z);
     if (want_cs) { grid1.x += (g.cs_N + 63) / 64; cs_done = true; }   // column-sum blocks ride in the same launch, first
     if (lean) {
+      static const bool remap_off = [] { const char* e = getenv("GMK_GEMM_REMAP"); return e && e[0] == '0'; }();   // A/B knob
+      g.remap = remap_off ? 0 : 1;
       if (a_k && b_k) hipLaunchKernelGGL((gemm_f32_lean_kernel<true, true>), grid1, dim3(256), 0, s, g);
       else if (a_k) hipLaunchKernelGGL((gemm_f32_lean_kernel<true, false>), grid1, dim3(256), 0, s, g);
       else if (b_k) hipLaunchKernelGGL((gemm_f32_lean_kernel<false, true>), grid1, dim3(256), 0, s, g);
