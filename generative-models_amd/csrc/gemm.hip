@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 // Requires the contiguous extents to be multiples of 4 and 16-byte aligned bases (host checks); rows / K beyond the
 // problem are clamped for the load and zeroed on the way into LDS, so the loop is branch-free.
 #define GLD 68  // LDS row stride (floats) of a [GK][64] tile: 16-byte rows for ds_write_b128
+#define GLK (GK + 4)  // row stride of the lean kernel's row-major [64][GK] tiles: 16-byte rows, conflict-free ds_read_b128
 // a_kfast / b_kfast: the operand is contiguous along k.  (A variant that issued ALL loads of a block's 128 / 256 deep K
 // range up front was measured and dropped: 128+ VGPRs halve the blocks per CU and the dgrad shapes got 30-50 % slower.)
 // Bias gradient of nn.Linear (column sums of dy) as extra blocks of the weight-gradient launch: block `cb` sums 64
@@ -304,7 +305,8 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const GemmArgs g) {
 // Same chunk order and accumulation order as gemm_f32_pipe_kernel: bit-identical results.
 template <bool a_kfast, bool b_kfast>
 __global__ __launch_bounds__(256) void gemm_f32_lean_kernel(const GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float smem[2][2][GK * GLD];
+  constexpr int TSZ = GT * GLK > GK * GLD ? GT * GLK : GK * GLD;
+  __shared__ __attribute__((aligned(16))) float smem[2][2][TSZ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ncs = g.cs_src ? (g.cs_N + 63) / 64 : 0;
   int bid = blockIdx.x;
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256) void gemm_f32_lean_kernel(const GemmArgs g) {
       const int r = tid / 8 + 32 * u, kq = tid % 8;
       const int gi = min(i0 + r, g.M - 1);
       a_bo[u] = (unsigned)(((long long)gi * g.sai + kq * 4) * 4);
-      a_l[u] = kq * 4 * GLD + r;
+      a_l[u] = r * GLK + kq * 4;
     } else {
       const int k = tid / 16 + 16 * u, q = tid % 16;
       const int gi = min(i0 + q * 4, g.M - 4);
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(256) void gemm_f32_lean_kernel(const GemmArgs g) {
       const int r = tid / 8 + 32 * u, kq = tid % 8;
       const int gj = min(j0 + r, g.N - 1);
       b_bo[u] = (unsigned)(((long long)gj * g.sbj + kq * 4) * 4);
-      b_l[u] = kq * 4 * GLD + r;
+      b_l[u] = r * GLK + kq * 4;
     } else {
       const int k = tid / 16 + 16 * u, q = tid % 16;
       const int gj = min(j0 + q * 4, g.N - 4);
@@ -376,11 +378,9 @@ __global__ __launch_bounds__(256) void gemm_f32_lean_kernel(const GemmArgs g) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const float4 a = ar[u];
-      if (a_kfast) { float* d = As + a_l[u]; d[0] = a.x; d[GLD] = a.y; d[2 * GLD] = a.z; d[3 * GLD] = a.w; }
-      else *(float4*)(As + a_l[u]) = a;
+      *(float4*)(As + a_l[u]) = a;   // one ds_write_b128 either way: the tile's layout follows the operand's
       const float4 b = br[u];
-      if (b_kfast) { float* d = Bs + b_l[u]; d[0] = b.x; d[GLD] = b.y; d[2 * GLD] = b.z; d[3 * GLD] = b.w; }
-      else *(float4*)(Bs + b_l[u]) = b;
+      *(float4*)(Bs + b_l[u]) = b;
     }
   };
   f32x16 acc;
@@ -389,11 +389,26 @@ __global__ __launch_bounds__(256) void gemm_f32_lean_kernel(const GemmArgs g) {
   auto mfma_chunk = [&](int buf) {
     const float* As = smem[buf][0];
     const float* Bs = smem[buf][1];
+    // The LDS tile of an operand follows its memory layout, so that every global float4 is ONE ds_write_b128:
+    //   k-contiguous operand -> row-major tile [64][GK + 4]: a lane reads 4 consecutive k of its row at once (ds_read_b128,
+    //     1 LDS cycle per MFMA and operand);
+    //   row-contiguous operand -> k-major tile [GK][68]: one ds_read_b32 per MFMA.
+    // (Both operands k-major, as in gemm_f32_pipe_kernel, cost 8 LDS cycles per MFMA -- the compiler pairs the reads into
+    // ds_read2_b32 -- which with 12 waves per CU keeps the LDS busy for half of every MFMA slot; PMC: matrix pipe 55-58 %.)
+    // Which k sits at which MFMA k index is free as long as A and B agree: lane half h takes k = 8m + 4h + j in step (m, j).
+    const float* ap = a_kfast ? As + (wr * 32 + l31) * GLK + 4 * h : As + 4 * h * GLD + wr * 32 + l31;
+    const float* bp = b_kfast ? Bs + (wc * 32 + l31) * GLK + 4 * h : Bs + 4 * h * GLD + wc * 32 + l31;
 #pragma unroll
-    for (int s = 0; s < GK / 2; ++s) {
-      const float a = As[(2 * s + h) * GLD + wr * 32 + l31];
-      const float b = Bs[(2 * s + h) * GLD + wc * 32 + l31];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    for (int m = 0; m < GK / 8; ++m) {
+      float4 a, b;
+      if (a_kfast) a = *(const float4*)(ap + 8 * m);
+      else a = make_float4(ap[8 * m * GLD], ap[(8 * m + 1) * GLD], ap[(8 * m + 2) * GLD], ap[(8 * m + 3) * GLD]);
+      if (b_kfast) b = *(const float4*)(bp + 8 * m);
+      else b = make_float4(bp[8 * m * GLD], bp[(8 * m + 1) * GLD], bp[(8 * m + 2) * GLD], bp[(8 * m + 3) * GLD]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
     }
   };
 #pragma unroll
