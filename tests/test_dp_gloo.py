@@ -201,3 +201,16 @@ def test_fused_adamw_is_a_torch_adamw_with_reference_state_layout():
     assert a["param_groups"][0].keys() == b["param_groups"][0].keys()
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=10)
     assert "last_epoch" in sched.state_dict()
+
+
+def test_dp_rank_raises_the_hip_hardware_queue_count(monkeypatch):
+    """gmk.parallel.ensure_hw_queues: a data-parallel rank wants 8 HIP hardware queues (with the default 4, RCCL's queues
+    put a weight-gradient stream on the main stream's queue: +17 % per step, profiles/r03_dp_rehearsal.txt); a larger
+    setting of the user's is left alone."""
+    from gmk import parallel
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
+    assert parallel.ensure_hw_queues() == 8 and os.environ["GPU_MAX_HW_QUEUES"] == "8"
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "16")
+    assert parallel.ensure_hw_queues() == 16 and os.environ["GPU_MAX_HW_QUEUES"] == "16"
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+    assert parallel.ensure_hw_queues() == 8 and os.environ["GPU_MAX_HW_QUEUES"] == "8"
