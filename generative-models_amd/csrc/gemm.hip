@@ -297,12 +297,13 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(const GemmArgs g) {
 // PMC of gemm_f32_pipe_kernel at the configs[4] FC shapes: 5-7 VALU instructions per MFMA (per-chunk 64-bit address
 // arithmetic, end-of-K clamps, zero selects), and fp32 MFMA shares the VALU issue port: matrix pipe 44-58 % busy whatever
 // the tile shape.  Here every per-lane address is a 32-bit byte offset computed ONCE and the chunk's position is a uniform
-// base pointer (global_load ... saddr form: no vector instruction per load); nothing is clamped or zeroed per lane:
+// base pointer (scalar arithmetic + one 64-bit vector add per load); nothing is clamped or zeroed per lane:
 //   - rows / columns of a ragged edge tile re-read a valid row: they only reach accumulator rows / columns that are
 //     never written (an MFMA row depends on its own A row only);
 //   - the K range of every block is a whole number of chunks (host: K % 32 == 0), chunks of the prefetch ring past the
 //     end re-read the last chunk and are never multiplied (uniform guard around the MFMA section).
-// Same chunk order and accumulation order as gemm_f32_pipe_kernel: bit-identical results.
+// Chunks in the same order as gemm_f32_pipe_kernel; inside a chunk the k pairs are taken in another order (mfma_chunk
+// below), so results differ from it in the last bits (same fp32 FMA chain length, fixed order: deterministic).
 template <bool a_kfast, bool b_kfast>
 __global__ __launch_bounds__(256) void gemm_f32_lean_kernel(const GemmArgs g) {
   constexpr int TSZ = GT * GLK > GK * GLD ? GT * GLK : GK * GLD;
